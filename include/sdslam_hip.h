@@ -1,0 +1,121 @@
+/* sdslam_hip.h -- C ABI of libsdslam_hip.so: the MI355X (gfx950) implementation of SD-SLAM's
+ * per-frame tracking hot path.  Plain pointers and sizes only; every entry point returns an
+ * int32 status (SD_OK = 0) and never throws.  Opaque handles own device memory and one HIP
+ * stream; calls on one handle are serialised by the caller, different handles are independent
+ * (re-entrancy contract of SURVEY.md §8b: Tracking thread + LoopClosing thread).
+ *
+ * Each group cites the reference C++ interface it replaces (paths relative to the reference
+ * repository pasensio97/SDslam); INTEGRATION.md shows the reference-side binding.
+ */
+#ifndef SDSLAM_HIP_H_
+#define SDSLAM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_OK 0
+#define SD_ERR_INVALID_ARG 1  /* bad pointer/size/shape                                   */
+#define SD_ERR_HIP 2          /* a HIP runtime call failed (see sd_last_error)             */
+#define SD_ERR_CAPACITY 3     /* caller buffer / handle capacity too small                  */
+#define SD_ERR_NO_DEVICE 4    /* no gfx950 device visible                                   */
+#define SD_FALSE 100          /* the reference would have returned `false` / an empty Mat   */
+
+const char* sd_last_error(void);      /* thread-local description of the last failure      */
+int sd_device_count(void);            /* number of visible HIP devices (0 on a CPU box)    */
+const char* sd_version(void);
+
+/* cv::KeyPoint, 28 bytes: {pt.x, pt.y, size, angle, response, octave, class_id} */
+typedef struct sd_keypoint {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} sd_keypoint;
+
+/* ------------------------------------------------------------------------------------------
+ * ORB extractor -- replaces SD_SLAM::ORBextractor
+ *   ctor            src/ORBextractor.h:38,   src/ORBextractor.cc:406-457
+ *   operator()      src/ORBextractor.h:45-46, src/ORBextractor.cc:620-678
+ *   Get*()          src/ORBextractor.h:48-70
+ * One handle serves frames up to max_w x max_h, at most max_batch frames per call.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sd_orb sd_orb;
+
+int sd_orb_create(int nfeatures, float scale_factor, int nlevels, int th_fast,
+                  int max_w, int max_h, int max_batch, int device, sd_orb** out);
+void sd_orb_destroy(sd_orb* h);
+
+/* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (arrays of nlevels floats; any pointer may be NULL). */
+int sd_orb_levels(const sd_orb* h);
+int sd_orb_scale_tables(const sd_orb* h, float* sf, float* inv_sf, float* sigma2, float* inv_sigma2);
+int sd_orb_features_per_level(const sd_orb* h, int32_t* quota);
+
+/* Host-only geometry query (works without a GPU): per level {w, h, quota, levelCols, levelRows,
+ * cellW, cellH, nfeaturesCell} (src/ORBextractor.cc:472-488,683) and per cell {level, zone x0,
+ * y0, w, h, evaluated} (the FAST detection zone of src/ORBextractor.cc:501-536). */
+int sd_orb_plan_info(int nfeatures, float scale_factor, int nlevels, int th_fast, int w, int hgt,
+                     int32_t* level_info /* nlevels x 8 */, int32_t* cell_zones /* cap x 6, may be NULL */,
+                     int cell_cap, int32_t* n_cells, uint64_t* bytes_per_frame);
+
+/* operator()(image, mask(ignored), keypoints, descriptors, pyramid): one 8-bit grey frame in
+ * host memory -> keypoints (cap entries), descriptors (cap x 32 bytes), *n_out.  The image
+ * pyramid stays resident on the device (sd_orb_level_*).  Empty image => *n_out = 0, SD_OK
+ * (src/ORBextractor.cc:622-623). */
+int sd_orb_extract(sd_orb* h, const uint8_t* img, int w, int hgt, int stride,
+                   sd_keypoint* kps_out, uint8_t* desc_out, int cap, int* n_out);
+
+/* Batched-frames mode: n_frames independent frames of identical size.
+ * Host variant copies in/out; device variant takes a device pointer, launches asynchronously
+ * on the handle's stream and leaves the results resident (read them with sd_orb_download or
+ * chain into sd_match_ / sd_align_ calls on the same handle). */
+int sd_orb_extract_batch(sd_orb* h, const uint8_t* imgs, int n_frames, int w, int hgt, int stride,
+                         size_t frame_stride, sd_keypoint* kps_out, uint8_t* desc_out,
+                         int cap_per_frame, int32_t* n_out);
+int sd_orb_extract_batch_device(sd_orb* h, const void* d_imgs, int n_frames, int w, int hgt,
+                                int stride, size_t frame_stride);
+int sd_orb_download(sd_orb* h, int frame0, int n_frames, sd_keypoint* kps_out, uint8_t* desc_out,
+                    int cap_per_frame, int32_t* n_out);
+
+/* std::vector<cv::Mat>& imagePyramid of operator(): level geometry and a host copy of one
+ * level of one frame of the last batch (padded != 0: including the 19-px REFLECT_101 border
+ * the reference keeps around each level, src/ORBextractor.cc:684-697). */
+int sd_orb_level_info(const sd_orb* h, int level, int* w, int* hgt);
+int sd_orb_level_copy(sd_orb* h, int frame, int level, int padded, uint8_t* out, int out_stride);
+
+/* Diagnostics used by the parity tests (stage outputs of the last batch). */
+int sd_orb_debug_blurred(sd_orb* h, int frame, int level, uint8_t* out, int out_stride);
+int sd_orb_debug_cell_counts(sd_orb* h, int frame, int level, int32_t* out, int cap, int* n_cells);
+int sd_orb_debug_level_keys(sd_orb* h, int frame, int level, uint32_t* keys_out, int cap, int* n);
+
+/* Stream / timing plumbing (bench + rocprof).  sd_orb_set_stream: run on a caller-owned
+ * hipStream_t (NULL restores the handle's own stream).  With profiling on, every extract call
+ * brackets each stage with HIP events on the launch stream; sd_orb_stage_ms returns the
+ * elapsed ms of the last call per stage (names from sd_orb_stage_name). */
+int sd_orb_set_stream(sd_orb* h, void* hip_stream);
+int sd_orb_sync(sd_orb* h);
+int sd_orb_set_profiling(sd_orb* h, int on);
+int sd_orb_num_stages(void);
+const char* sd_orb_stage_name(int stage);
+int sd_orb_stage_ms(sd_orb* h, float* ms_out, int cap);
+/* algorithmic bytes per frame of each stage for the current geometry */
+int sd_orb_stage_bytes(const sd_orb* h, double* bytes_out, int cap);
+
+/* device memory helpers for harnesses that have no HIP binding of their own */
+int sd_dev_alloc(size_t bytes, void** out);
+int sd_dev_free(void* p);
+int sd_dev_upload(void* dst, const void* src, size_t bytes);
+int sd_dev_download(void* dst, const void* src, size_t bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * ORBmatcher::DescriptorDistance -- src/ORBmatcher.h:44, src/ORBmatcher.cc:1459-1473
+ * (pure host function; kept in the ABI so callers need no second library)
+ * ------------------------------------------------------------------------------------------ */
+int sd_hamming(const uint8_t* a32, const uint8_t* b32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDSLAM_HIP_H_ */

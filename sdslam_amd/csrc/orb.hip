@@ -1,0 +1,1070 @@
+// ORB extraction on MI355X (gfx950): hand-written HIP kernels + the sd_orb_* C ABI.
+//
+// Replaces SD_SLAM::ORBextractor (reference src/ORBextractor.cc).  Batched-frames-first:
+// every kernel takes the frame index as its outermost grid dimension, so one launch covers
+// all frames of a batch (and, for FAST / blur / descriptors, all pyramid levels).
+//
+//   k_pyr_level      ComputePyramid                src/ORBextractor.cc:680-700 (resize + REFLECT_101 border, one pass)
+//   k_fast_cells     cv::FAST per grid cell        src/ORBextractor.cc:501-552 (FAST-9/16, score, cell-local 3x3 NMS)
+//   k_select_level   quota loop + retainBest       src/ORBextractor.cc:554-605 (libstdc++ introselect replay)
+//   k_blur           GaussianBlur 7x7 s=2          src/ORBextractor.cc:659-660 (8-bit fixed point, separable)
+//   k_orient_desc    IC_Angle + steered rBRIEF     src/ORBextractor.cc:78-143, 608-618, 669-674
+//
+// HBM layout (per frame): padded pyramid block (all levels, 19-px border, 64-B aligned rows),
+// blurred block (same geometry), candidate keys (u32: response<<24 | y<<12 | x, per cell, raster
+// order), selected keys per level, output keypoints (28 B) + descriptors (32 B).
+// Integer / byte work, HBM-bound: no MFMA anywhere (largest dense object is 7 taps).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "introselect.h"
+#include "orb_plan.h"
+#include "sd_common.h"
+#include "sd_sincosf.h"
+
+namespace sd {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if ((unsigned)p < (unsigned)len) return p;
+  if (len == 1) return 0;
+  do {
+    if (p < 0) p = -p;
+    else p = 2 * len - 2 - p;
+  } while ((unsigned)p >= (unsigned)len);
+  return p;
+}
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+  unsigned lane = __lane_id();
+  return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pyr_level: one pyramid level, written over its whole padded domain in a single pass.
+// level 0 : copyMakeBorder(image, REFLECT_101)
+// level l : resize(level l-1 -> l, INTER_LINEAR) then copyMakeBorder(REFLECT_101|ISOLATED);
+//           a border pixel equals the resize result of its reflected interior pixel.
+// Each thread produces 4 horizontally adjacent bytes (one u32 store, coalesced).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_level(const OrbPlan* __restrict__ P, int level,
+                                                   const uint8_t* __restrict__ src0, int src_stride,
+                                                   size_t src_frame_stride, uint8_t* __restrict__ pyr,
+                                                   const int32_t* __restrict__ coef) {
+  const LevelGeom L = P->lv[level];
+  const int frame = blockIdx.z;
+  const int px = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int py = blockIdx.y * 4 + threadIdx.y;
+  if (px >= L.pstride || py >= L.prows) return;
+  uint8_t* dstbase = pyr + (size_t)frame * P->pyr_frame_bytes + L.off;
+  const int Y = reflect101(py - SD_EDGE, L.h);
+  uint32_t packed = 0;
+  if (level == 0) {
+    const uint8_t* s = src0 + (size_t)frame * src_frame_stride + (size_t)Y * src_stride;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int x = px + k;
+      uint32_t v = 0;
+      if (x < L.w + 2 * SD_EDGE) v = s[reflect101(x - SD_EDGE, L.w)];
+      packed |= v << (8 * k);
+    }
+  } else {
+    const LevelGeom S = P->lv[level - 1];
+    const uint8_t* sb = pyr + (size_t)frame * P->pyr_frame_bytes + S.off + (size_t)SD_EDGE * S.pstride + SD_EDGE;
+    if (L.area2x2) {
+      const uint8_t* r0 = sb + (size_t)(2 * Y) * S.pstride;
+      const uint8_t* r1 = r0 + S.pstride;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int x = px + k;
+        uint32_t v = 0;
+        if (x < L.w + 2 * SD_EDGE) {
+          int X = reflect101(x - SD_EDGE, L.w);
+          v = (r0[2 * X] + r0[2 * X + 1] + r1[2 * X] + r1[2 * X + 1] + 2) >> 2;
+        }
+        packed |= v << (8 * k);
+      }
+    } else {
+      const int32_t* xo = coef + L.cx;
+      const int32_t* xa = xo + L.w;
+      const int32_t* yo = coef + L.cy;
+      const int32_t* yb = yo + L.h;
+      int sy0 = yo[Y], sy1 = sy0 + 1;
+      sy0 = sy0 < 0 ? 0 : (sy0 < S.h ? sy0 : S.h - 1);
+      sy1 = sy1 < 0 ? 0 : (sy1 < S.h ? sy1 : S.h - 1);
+      const int bb = yb[Y];
+      const int b0 = (int)(short)(bb & 0xffff), b1 = (int)(short)((unsigned)bb >> 16);
+      const uint8_t* r0 = sb + (size_t)sy0 * S.pstride;
+      const uint8_t* r1 = sb + (size_t)sy1 * S.pstride;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int x = px + k;
+        uint32_t v = 0;
+        if (x < L.w + 2 * SD_EDGE) {
+          int X = reflect101(x - SD_EDGE, L.w);
+          int sx = xo[X];
+          int sx1 = sx + 1 < S.w ? sx + 1 : S.w - 1;
+          int aa = xa[X];
+          int a0 = (int)(short)(aa & 0xffff), a1 = (int)(short)((unsigned)aa >> 16);
+          int h0 = r0[sx] * a0 + r0[sx1] * a1;
+          int h1 = r1[sx] * a0 + r1[sx1] * a1;
+          int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+          v = (uint32_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+        }
+        packed |= v << (8 * k);
+      }
+    }
+  }
+  *(uint32_t*)(dstbase + (size_t)py * L.pstride + px) = packed;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fast_cells: one workgroup per (grid cell, frame).  cv::FAST(cellImage, kps, th, true):
+// corner test (>= 9 contiguous ring pixels brighter than v+t or darker than v-t), score =
+// max over the 16 nine-arcs of min |v - p| minus 1, strict-greater 3x3 NMS in which pixels
+// outside the cell's detection zone count as score 0, survivors emitted in
+// raster order (the order cv::FAST produces and retainBest's tie-breaking depends on).
+// The cell (+3 px ring halo) is staged once through LDS in aligned 4-byte words; scores live in
+// a byte map in LDS; ordered emission uses wave ballots over wave-contiguous pixel ranges.
+// ------------------------------------------------------------------------------------------
+template <int SH>
+__device__ __forceinline__ int sh_idx(int k) { return (k + SH) & 15; }
+
+__device__ __forceinline__ int fast_score(const uint8_t* __restrict__ c, int tp, int th) {
+  // ring offsets (dx,dy), clockwise from (0,3): SURVEY App. A1
+  const int v = c[0];
+  int d[16];
+  d[0] = v - c[3 * tp];
+  d[1] = v - c[3 * tp + 1];
+  d[2] = v - c[2 * tp + 2];
+  d[3] = v - c[tp + 3];
+  d[4] = v - c[3];
+  d[5] = v - c[-tp + 3];
+  d[6] = v - c[-2 * tp + 2];
+  d[7] = v - c[-3 * tp + 1];
+  d[8] = v - c[-3 * tp];
+  d[9] = v - c[-3 * tp - 1];
+  d[10] = v - c[-2 * tp - 2];
+  d[11] = v - c[-tp - 3];
+  d[12] = v - c[-3];
+  d[13] = v - c[tp - 3];
+  d[14] = v - c[2 * tp - 2];
+  d[15] = v - c[3 * tp - 1];
+  // quick reject on the 4 compass pairs, then the full 9-contiguous test on bit masks
+  unsigned dark = 0, bright = 0;   // dark: p < v - th  <=> d > th ; bright: p > v + th <=> d < -th
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    dark |= (unsigned)(d[k] > th) << k;
+    bright |= (unsigned)(d[k] < -th) << k;
+  }
+  unsigned md = dark | (dark << 16), mb = bright | (bright << 16);
+  unsigned rd = md & (md >> 1);
+  rd &= rd >> 2;
+  rd &= rd >> 4;
+  rd &= md >> 8;
+  unsigned rb = mb & (mb >> 1);
+  rb &= rb >> 2;
+  rb &= rb >> 4;
+  rb &= mb >> 8;
+  if (((rd | rb) & 0xffffu) == 0) return 0;
+  // score = max(max_arc min d, max_arc min(-d)) - 1  (== cornerScore<16>; >= th for a corner)
+  int m2[16], m4[16], M2[16], M4[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    m2[k] = min(d[k], d[(k + 1) & 15]);
+    M2[k] = max(d[k], d[(k + 1) & 15]);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    m4[k] = min(m2[k], m2[(k + 2) & 15]);
+    M4[k] = max(M2[k], M2[(k + 2) & 15]);
+  }
+  int a = -255, b = 255;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    int m9 = min(min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]);
+    int M9 = max(max(M4[k], M4[(k + 4) & 15]), d[(k + 8) & 15]);
+    a = max(a, m9);
+    b = min(b, M9);
+  }
+  return max(a, -b) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ P,
+                                                    const CellGeom* __restrict__ cells,
+                                                    const uint8_t* __restrict__ pyr,
+                                                    uint32_t* __restrict__ cand,
+                                                    int32_t* __restrict__ cell_count) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int wcnt[4];
+  const CellGeom C = cells[blockIdx.x];
+  const int frame = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (C.zw <= 0 || C.zh <= 0) {
+    if (tid == 0) cell_count[(size_t)frame * P->ncells + blockIdx.x] = 0;
+    return;
+  }
+  const LevelGeom L = P->lv[C.level];
+  const uint8_t* img = pyr + (size_t)frame * P->pyr_frame_bytes + L.off;
+  uint32_t* out = cand + (size_t)frame * P->cand_per_frame + C.cand_off;
+  const int th = P->thFAST;
+  const int zw = C.zw, zh = C.zh, S = C.strip_rows;
+  const int xs = C.zx0 - 3 + SD_EDGE;   // padded x of tile column 0 (before alignment)
+  const int xa = xs & ~3, sh = xs - xa;
+  const int TPW = (sh + zw + 6 + 3) >> 2;   // tile pitch in 4-byte words
+  const int TP = TPW * 4;
+  const int SP = (zw + 2 + 3) & ~3;         // score-map pitch (bytes)
+  uint8_t* tile = smem;
+  uint8_t* sc = smem + (size_t)TP * (S + 2 + 6);
+  int total = 0;
+
+  for (int r0 = 0; r0 < zh; r0 += S) {
+    const int r1 = min(r0 + S, zh);
+    const int sr0 = max(r0 - 1, 0), sr1 = min(r1 + 1, zh);   // zone rows whose scores are needed
+    const int nsr = sr1 - sr0;
+    const int npr = nsr + 6;
+    // ---- stage pixels: padded rows (zy0 + sr0 - 3 + 19) .. , aligned words
+    {
+      const uint8_t* g = img + (size_t)(C.zy0 + sr0 - 3 + SD_EDGE) * L.pstride + xa;
+      const int nwords = npr * TPW;
+      for (int i = tid; i < nwords; i += 256) {
+        int row = i / TPW, wc = i - row * TPW;
+        ((uint32_t*)tile)[i] = *(const uint32_t*)(g + (size_t)row * L.pstride + wc * 4);
+      }
+      const int nsc = ((nsr + 2) * SP) >> 2;
+      for (int i = tid; i < nsc; i += 256) ((uint32_t*)sc)[i] = 0;
+    }
+    __syncthreads();
+    // ---- corner test + score for every zone pixel of the needed rows
+    {
+      const int n = nsr * zw;
+      for (int q = tid; q < n; q += 256) {
+        int y = q / zw, x = q - y * zw;
+        const uint8_t* c = tile + (y + 3) * TP + x + 3 + sh;
+        int s = fast_score(c, TP, th);
+        if (s > 0) sc[(y + 1) * SP + x + 1] = (uint8_t)s;
+      }
+    }
+    __syncthreads();
+    // ---- NMS + ordered emission (wave w owns a contiguous raster range of the strip)
+    {
+      const int npx = (r1 - r0) * zw;
+      const int Q = (((npx + 3) >> 2) + 63) & ~63;
+      const int nj = Q >> 6;
+      unsigned long long bits = 0;
+      int cnt = 0;
+      for (int j = 0; j < nj; j++) {
+        int q = wave * Q + j * 64 + lane;
+        bool keep = false;
+        if (q < npx) {
+          int ry = q / zw, x = q - ry * zw;
+          const uint8_t* p = sc + (r0 + ry - sr0 + 1) * SP + x + 1;
+          int s = p[0];
+          keep = s > 0 && s > p[-1] && s > p[1] && s > p[-SP - 1] && s > p[-SP] && s > p[-SP + 1] &&
+                 s > p[SP - 1] && s > p[SP] && s > p[SP + 1];
+        }
+        unsigned long long m = __ballot(keep);
+        cnt += __popcll(m);
+        bits |= (unsigned long long)keep << j;
+      }
+      if (lane == 0) wcnt[wave] = cnt;
+      __syncthreads();
+      int base = total;
+      for (int w = 0; w < wave; w++) base += wcnt[w];
+      const int strip_total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      const unsigned long long lt = lanemask_lt();
+      for (int j = 0; j < nj; j++) {
+        bool keep = (bits >> j) & 1ull;
+        unsigned long long m = __ballot(keep);
+        if (keep) {
+          int q = wave * Q + j * 64 + lane;
+          int ry = q / zw, x = q - ry * zw;
+          int s = sc[(r0 + ry - sr0 + 1) * SP + x + 1];
+          unsigned pos = (unsigned)(base + __popcll(m & lt));
+          if (pos < C.cap)
+            out[pos] = ((uint32_t)s << 24) | ((uint32_t)(C.zy0 + r0 + ry) << 12) | (uint32_t)(C.zx0 + x);
+        }
+        base += __popcll(m);
+      }
+      total += strip_total;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) cell_count[(size_t)frame * P->ncells + blockIdx.x] = min(total, (int)C.cap);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_select_level: one workgroup per (level, frame).
+//   1. quota redistribution loop            src/ORBextractor.cc:541-575 (serial, lane 0)
+//   2. per-cell retainBest + resize         :586-588   (one lane per cell, introselect replay)
+//   3. concatenation in cell raster order   :591-597
+//   4. level-wide retainBest + resize       :601-604   (lane 0)
+// Candidate lists are staged in LDS when the level fits, else processed in place in HBM.
+// ------------------------------------------------------------------------------------------
+#define SEL_WORK_CAP 8192
+#define SEL_LIST_CAP 4096
+#define SEL_MAX_CELLS 1024
+
+__global__ __launch_bounds__(256) void k_select_level(const OrbPlan* __restrict__ P,
+                                                      const CellGeom* __restrict__ cells,
+                                                      uint32_t* __restrict__ cand,
+                                                      const int32_t* __restrict__ cell_count,
+                                                      uint32_t* __restrict__ lvl_scratch,
+                                                      uint32_t* __restrict__ sel,
+                                                      int32_t* __restrict__ sel_count) {
+  __shared__ uint32_t s_work[SEL_WORK_CAP];
+  __shared__ uint32_t s_list[SEL_LIST_CAP];
+  __shared__ int s_total[SEL_MAX_CELLS];
+  __shared__ int s_retain[SEL_MAX_CELLS];
+  __shared__ int s_off[SEL_MAX_CELLS + 1];   // work offsets, then kept offsets
+  __shared__ int s_flag;
+  const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+  const LevelGeom L = P->lv[level];
+  int32_t* out_n = sel_count + (size_t)frame * P->nlevels + level;
+  if (L.ncells <= 0 || L.quota <= 0) {
+    if (tid == 0) *out_n = 0;
+    return;
+  }
+  const int nC = L.ncells;
+  const CellGeom* cg = cells + L.cell0;
+  const int32_t* cc = cell_count + (size_t)frame * P->ncells + L.cell0;
+  uint32_t* gcand = cand + (size_t)frame * P->cand_per_frame;
+
+  for (int c = tid; c < nC; c += 256) s_total[c] = cc[c];
+  __syncthreads();
+  if (tid == 0) {
+    // quota loop (serial by definition)
+    const int nfc = L.nfeaturesCell;
+    int nNoMore = 0, nToDistribute = 0;
+    for (int c = 0; c < nC; c++) {
+      int nKeys = s_total[c];
+      if (!cg[c].evaluated) {          // reference `continue`s: nToRetain=0, bNoMore=false
+        s_retain[c] = 0;
+        s_off[c] = 0;                  // bNoMore flag lives in s_off during the loop
+        continue;
+      }
+      if (nKeys > nfc) {
+        s_retain[c] = nfc;
+        s_off[c] = 0;
+      } else {
+        s_retain[c] = nKeys;
+        nToDistribute += nfc - nKeys;
+        s_off[c] = 1;
+        nNoMore++;
+      }
+    }
+    while (nToDistribute > 0 && nNoMore < nC) {
+      // nfeaturesCell + ceil((float)nToDistribute/(nCells-nNoMore))
+      int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nC - nNoMore));
+      nToDistribute = 0;
+      for (int c = 0; c < nC; c++) {
+        if (!s_off[c]) {
+          if (s_total[c] > nNew) {
+            s_retain[c] = nNew;
+          } else {
+            s_retain[c] = s_total[c];
+            nToDistribute += nNew - s_total[c];
+            s_off[c] = 1;
+            nNoMore++;
+          }
+        }
+      }
+    }
+    // work offsets + kept counts
+    int wo = 0, kept = 0;
+    for (int c = 0; c < nC; c++) {
+      s_off[c] = wo;
+      wo += s_total[c];
+      kept += min(s_total[c], s_retain[c]);
+    }
+    s_off[nC] = wo;
+    s_flag = (wo <= SEL_WORK_CAP ? 1 : 0) | (kept <= SEL_LIST_CAP ? 2 : 0);
+  }
+  __syncthreads();
+  const bool work_lds = s_flag & 1, list_lds = s_flag & 2;
+  // stage candidates into LDS (cell lists become contiguous)
+  if (work_lds) {
+    for (int c = 0; c < nC; c++) {
+      const uint32_t* src = gcand + cg[c].cand_off;
+      const int n = s_total[c], o = s_off[c];
+      for (int i = tid; i < n; i += 256) s_work[o + i] = src[i];
+    }
+  }
+  __syncthreads();
+  // per-cell retainBest (one lane per cell)
+  for (int c = tid; c < nC; c += 256) {
+    int n = s_total[c], keep = s_retain[c];
+    if (n > keep && keep > 0) {
+      uint32_t* a = work_lds ? (s_work + s_off[c]) : (gcand + cg[c].cand_off);
+      sdsel::nth_element(a, n, keep);
+    }
+  }
+  __syncthreads();
+  // kept offsets (serial prefix, tiny) -- reuse s_retain as kept count
+  if (tid == 0) {
+    int o = 0;
+    for (int c = 0; c < nC; c++) {
+      int k = min(s_total[c], s_retain[c]);
+      s_retain[c] = k;
+      s_total[c] = o;   // kept offset
+      o += k;
+    }
+    s_flag = o;          // M
+  }
+  __syncthreads();
+  const int M = s_flag;
+  uint32_t* list = list_lds ? s_list : (lvl_scratch + (size_t)frame * P->cand_per_frame + L.cand_off);
+  for (int c = 0; c < nC; c++) {
+    const uint32_t* a = work_lds ? (s_work + s_off[c]) : (gcand + cg[c].cand_off);
+    const int k = s_retain[c], o = s_total[c];
+    for (int i = tid; i < k; i += 256) list[o + i] = a[i];
+  }
+  __syncthreads();
+  int Mout = M;
+  if (M > L.quota) {
+    if (tid == 0) sdsel::nth_element(list, M, L.quota);
+    Mout = L.quota;
+  }
+  __syncthreads();
+  uint32_t* dst = sel + (size_t)frame * P->nsel + L.sel_off;
+  for (int i = tid; i < Mout; i += 256) dst[i] = list[i];
+  if (tid == 0) *out_n = Mout;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_blur: GaussianBlur(7x7, sigma 2, REFLECT_101) in OpenCV's 8-bit fixed point: integer taps
+// round(g*256) = {18,34,49,55,49,34,18}, row pass in int32, column pass (sum + 2^15) >> 16,
+// saturated.  The padded pyramid already holds the REFLECT_101 border, so no border logic.
+// One 64x16 output tile per workgroup; only levels that own keypoints are blurred
+// (src/ORBextractor.cc:655-660).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, const BlurTile* __restrict__ tiles,
+                                              const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                              const int32_t* __restrict__ sel_count) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_in[22][80];
+  __shared__ uint16_t s_h[22][64];
+  const BlurTile T = tiles[blockIdx.x];
+  const int frame = blockIdx.y, tid = threadIdx.x;
+  if (sel_count[(size_t)frame * P->nlevels + T.level] <= 0) return;
+  const LevelGeom L = P->lv[T.level];
+  const size_t fo = (size_t)frame * P->pyr_frame_bytes + L.off;
+  const uint8_t* src = pyr + fo;
+  // tile origin: interior (tx*64, ty*16) -> padded (tx*64 + 19, ty*16 + 19); taps reach -3..+3
+  const int px0 = T.tx * 64 + SD_EDGE - 3;   // = tx*64 + 16 : 16-byte aligned
+  const int py0 = T.ty * 16 + SD_EDGE - 3;
+  for (int i = tid; i < 22 * 18; i += 256) {   // 18 words = 72 bytes per row
+    int r = i / 18, wc = i - r * 18;
+    int gy = min(py0 + r, L.prows - 1);
+    int gx = px0 + wc * 4;
+    uint32_t v = 0;
+    if (gx + 3 < L.pstride) v = *(const uint32_t*)(src + (size_t)gy * L.pstride + gx);
+    *(uint32_t*)(&s_in[r][wc * 4]) = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < 22 * 64; i += 256) {
+    int r = i >> 6, x = i & 63;
+    const uint8_t* p = &s_in[r][x];
+    int s = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
+    s_h[r][x] = (uint16_t)s;   // <= 255*257 = 65535
+  }
+  __syncthreads();
+  uint8_t* dst = blur + fo;
+  for (int i = tid; i < 16 * 64; i += 256) {
+    int y = i >> 6, x = i & 63;
+    int X = T.tx * 64 + x, Y = T.ty * 16 + y;
+    if (X < L.w && Y < L.h) {
+      int s = 18 * ((int)s_h[y][x] + s_h[y + 6][x]) + 34 * ((int)s_h[y + 1][x] + s_h[y + 5][x]) +
+              49 * ((int)s_h[y + 2][x] + s_h[y + 4][x]) + 55 * (int)s_h[y + 3][x];
+      int v = (s + (1 << 15)) >> 16;
+      dst[(size_t)(Y + SD_EDGE) * L.pstride + X + SD_EDGE] = (uint8_t)(v > 255 ? 255 : v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_orient_desc: one wavefront per selected keypoint.
+//   IC_Angle: integer moments over the r=15 disc (umax table), fastAtan2 polynomial in f32.
+//   rBRIEF : a = cosf(angle*pi/180), b = sinf(..) (host-libm-exact, sd_sincosf.h), 256 tests
+//            t0 < t1 on the blurred level at cvRound-rotated offsets; lane i evaluates tests
+//            i, i+64, i+128, i+192 so each __ballot is 8 descriptor bytes.
+//   Output keypoint: pt scaled by mvScaleFactor[level] AFTER description (:669-674).
+// Compiled with -ffp-contract=off: every float op below is a single IEEE operation.
+// ------------------------------------------------------------------------------------------
+__constant__ int8_t c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  const float eps = (float)2.2204460492503131e-16;
+  float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + eps);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + eps);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+__global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr,
+                                                     const uint8_t* __restrict__ blur,
+                                                     const uint32_t* __restrict__ sel,
+                                                     const int32_t* __restrict__ sel_count,
+                                                     sd_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                     int32_t* __restrict__ nout, int cap) {
+  const int frame = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  int g = blockIdx.x * 4 + (threadIdx.x >> 6);   // output slot of this wave
+  // locate (level, index) from the per-level counts (uniform scalar loop)
+  const int32_t* sc = sel_count + (size_t)frame * P->nlevels;
+  int level = -1, idx = 0, acc = 0;
+  for (int l = 0; l < P->nlevels; l++) {
+    int n = sc[l];
+    if (level < 0 && g < acc + n) {
+      level = l;
+      idx = g - acc;
+    }
+    acc += n;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) nout[frame] = min(acc, cap);
+  if (level < 0 || g >= cap) return;
+  const LevelGeom L = P->lv[level];
+  const uint32_t key = sel[(size_t)frame * P->nsel + L.sel_off + idx];
+  const int X = key & 0xfff, Y = (key >> 12) & 0xfff, resp = key >> 24;
+  const size_t fo = (size_t)frame * P->pyr_frame_bytes + L.off;
+  const int step = L.pstride;
+  const uint8_t* center = pyr + fo + (size_t)(Y + SD_EDGE) * step + X + SD_EDGE;
+
+  // ---- IC_Angle
+  int m10 = 0, m01 = 0;
+  {
+    const int u = (lane & 31) - 15;
+    const int half = lane >> 5;   // 0: rows +v, 1: rows -v
+    if ((lane & 31) < 31) {
+      for (int v = half; v <= 15; v++) {   // half 1 skips v = 0
+        if (abs(u) <= c_umax[v]) {
+          int val = half ? center[u - v * step] : center[u + v * step];
+          m10 += u * val;
+          m01 += (half ? -v : v) * val;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      m10 += __shfl_xor(m10, o);
+      m01 += __shfl_xor(m01, o);
+    }
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+  // ---- steered rBRIEF on the blurred level
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  const float arad = angle * factorPI;
+  const float a = sdsc::cosf_glibc(arad), b = sdsc::sinf_glibc(arad);
+  const uint8_t* bc = blur + fo + (size_t)(Y + SD_EDGE) * step + X + SD_EDGE;
+  unsigned long long words[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int t = j * 64 + lane;
+    const char4 pt = *(const char4*)(&c_pattern[t * 4]);
+    const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
+    // center[cvRound(x*b + y*a)*step + cvRound(x*a - y*b)]
+    const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
+    const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
+    const int t0 = bc[r0 * step + q0], t1 = bc[r1 * step + q1];
+    words[j] = __ballot(t0 < t1);
+  }
+  if (lane < 4) {
+    unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+    *(unsigned long long*)(desc + ((size_t)frame * cap + g) * 32 + lane * 8) = w;
+  }
+  if (lane == 0) {
+    sd_keypoint k;
+    float fx = (float)X, fy = (float)Y;
+    if (level != 0) {
+      fx = fx * L.scale;
+      fy = fy * L.scale;
+    }
+    k.x = fx;
+    k.y = fy;
+    k.size = L.kpsize;
+    k.angle = angle;
+    k.response = (float)resp;
+    k.octave = level;
+    k.class_id = -1;
+    kps[(size_t)frame * cap + g] = k;
+  }
+}
+
+}  // namespace sd
+
+// ==========================================================================================
+// host side: handle + C ABI
+// ==========================================================================================
+using namespace sd;
+
+enum { ST_PYR = 0, ST_FAST, ST_SELECT, ST_BLUR, ST_DESC, ST_COUNT };
+static const char* kStageNames[ST_COUNT] = {"pyramid", "fast_nms", "select", "blur", "orient_desc"};
+
+struct sd_orb {
+  int nfeatures, nlevels, thFAST;
+  float scaleFactor;
+  int max_w, max_h, max_batch, device;
+  HostPlan hp;
+  bool have_geom = false;
+  int cur_w = 0, cur_h = 0;
+  int last_frames = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  // device buffers
+  OrbPlan* d_plan = nullptr;
+  CellGeom* d_cells = nullptr;
+  BlurTile* d_tiles = nullptr;
+  int32_t* d_coef = nullptr;
+  uint8_t* d_img = nullptr;     // staging for host-input calls
+  uint8_t* d_pyr = nullptr;
+  uint8_t* d_blur = nullptr;
+  uint32_t* d_cand = nullptr;
+  uint32_t* d_scratch = nullptr;
+  int32_t* d_cell_count = nullptr;
+  uint32_t* d_sel = nullptr;
+  int32_t* d_sel_count = nullptr;
+  sd_keypoint* d_kps = nullptr;
+  uint8_t* d_desc = nullptr;
+  int32_t* d_nout = nullptr;
+  size_t cap_pyr = 0, cap_cand = 0, cap_cells = 0, cap_tiles = 0, cap_coef = 0;
+  bool profiling = false;
+  hipEvent_t ev[ST_COUNT + 1] = {};
+  float stage_ms[ST_COUNT] = {};
+};
+
+static int free_geom(sd_orb* h) {
+  void* ptrs[] = {h->d_cells, h->d_tiles, h->d_coef, h->d_pyr, h->d_blur, h->d_cand, h->d_scratch,
+                  h->d_cell_count, h->d_sel, h->d_sel_count};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  h->d_cells = nullptr; h->d_tiles = nullptr; h->d_coef = nullptr; h->d_pyr = nullptr; h->d_blur = nullptr;
+  h->d_cand = nullptr; h->d_scratch = nullptr; h->d_cell_count = nullptr; h->d_sel = nullptr; h->d_sel_count = nullptr;
+  return SD_OK;
+}
+
+static int ensure_geometry(sd_orb* h, int w, int hgt) {
+  if (h->have_geom && h->cur_w == w && h->cur_h == hgt) return SD_OK;
+  SD_REQUIRE(w <= h->max_w && hgt <= h->max_h, SD_ERR_CAPACITY, "frame larger than the handle's max_w x max_h");
+  const char* why = "";
+  if (!plan_geometry(h->nfeatures, h->nlevels, h->thFAST, w, hgt, h->hp, &why)) {
+    set_error(std::string("unsupported geometry: ") + why);
+    return SD_ERR_INVALID_ARG;
+  }
+  SD_REQUIRE(h->hp.max_cells_per_level <= SEL_MAX_CELLS, SD_ERR_INVALID_ARG, "too many grid cells per level");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  free_geom(h);
+  const HostPlan& hp = h->hp;
+  const size_t B = h->max_batch;
+  const size_t slack = 4096;
+  SD_HIP_CHECK(hipMalloc(&h->d_cells, std::max<size_t>(hp.cells.size(), 1) * sizeof(CellGeom)));
+  SD_HIP_CHECK(hipMalloc(&h->d_tiles, std::max<size_t>(hp.blur_tiles.size(), 1) * sizeof(BlurTile)));
+  SD_HIP_CHECK(hipMalloc(&h->d_coef, hp.coef.size() * sizeof(int32_t)));
+  SD_HIP_CHECK(hipMalloc(&h->d_pyr, hp.plan.pyr_frame_bytes * B + slack));
+  SD_HIP_CHECK(hipMalloc(&h->d_blur, hp.plan.pyr_frame_bytes * B + slack));
+  SD_HIP_CHECK(hipMalloc(&h->d_cand, std::max<size_t>(hp.plan.cand_per_frame, 1) * B * 4));
+  SD_HIP_CHECK(hipMalloc(&h->d_scratch, std::max<size_t>(hp.plan.cand_per_frame, 1) * B * 4));
+  SD_HIP_CHECK(hipMalloc(&h->d_cell_count, std::max<size_t>(hp.plan.ncells, 1) * B * 4));
+  SD_HIP_CHECK(hipMalloc(&h->d_sel, std::max<size_t>(hp.plan.nsel, 1) * B * 4));
+  SD_HIP_CHECK(hipMalloc(&h->d_sel_count, (size_t)h->nlevels * B * 4));
+  SD_HIP_CHECK(hipMemsetAsync(h->d_pyr, 0, hp.plan.pyr_frame_bytes * B + slack, h->stream));
+  SD_HIP_CHECK(hipMemsetAsync(h->d_blur, 0, hp.plan.pyr_frame_bytes * B + slack, h->stream));
+  if (!hp.cells.empty())
+    SD_HIP_CHECK(hipMemcpyAsync(h->d_cells, hp.cells.data(), hp.cells.size() * sizeof(CellGeom), hipMemcpyHostToDevice, h->stream));
+  if (!hp.blur_tiles.empty())
+    SD_HIP_CHECK(hipMemcpyAsync(h->d_tiles, hp.blur_tiles.data(), hp.blur_tiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice, h->stream));
+  SD_HIP_CHECK(hipMemcpyAsync(h->d_coef, hp.coef.data(), hp.coef.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  SD_HIP_CHECK(hipMemcpyAsync(h->d_plan, &hp.plan, sizeof(OrbPlan), hipMemcpyHostToDevice, h->stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  h->have_geom = true;
+  h->cur_w = w;
+  h->cur_h = hgt;
+  return SD_OK;
+}
+
+static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, size_t frame_stride) {
+  const HostPlan& hp = h->hp;
+  const OrbPlan& P = hp.plan;
+  hipStream_t s = h->stream;
+  const bool prof = h->profiling;
+  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[0], s));
+  for (int l = 0; l < P.nlevels; l++) {
+    const LevelGeom& L = P.lv[l];
+    dim3 grid((L.pstride + 255) / 256, (L.prows + 3) / 4, n), block(64, 4, 1);
+    hipLaunchKernelGGL(k_pyr_level, grid, block, 0, s, h->d_plan, l, d_imgs, stride, frame_stride, h->d_pyr, h->d_coef);
+  }
+  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[1], s));
+  if (P.ncells > 0) {
+    hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, n), dim3(256), hp.fast_lds_bytes, s, h->d_plan, h->d_cells,
+                       h->d_pyr, h->d_cand, h->d_cell_count);
+  }
+  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[2], s));
+  hipLaunchKernelGGL(k_select_level, dim3(P.nlevels, n), dim3(256), 0, s, h->d_plan, h->d_cells, h->d_cand,
+                     h->d_cell_count, h->d_scratch, h->d_sel, h->d_sel_count);
+  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[3], s));
+  hipLaunchKernelGGL(k_blur, dim3((unsigned)hp.blur_tiles.size(), n), dim3(256), 0, s, h->d_plan, h->d_tiles, h->d_pyr,
+                     h->d_blur, h->d_sel_count);
+  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[4], s));
+  const int cap = std::max(P.nsel, 1);
+  hipLaunchKernelGGL(k_orient_desc, dim3((cap + 3) / 4, n), dim3(256), 0, s, h->d_plan, h->d_pyr, h->d_blur, h->d_sel,
+                     h->d_sel_count, h->d_kps, h->d_desc, h->d_nout, cap);
+  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[5], s));
+  SD_HIP_CHECK(hipGetLastError());
+  h->last_frames = n;
+  return SD_OK;
+}
+
+extern "C" {
+
+const char* sd_last_error(void) { return g_err.c_str(); }
+const char* sd_version(void) { return "sdslam_hip 0.1 (gfx950)"; }
+
+int sd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sd_orb_create(int nfeatures, float scale_factor, int nlevels, int th_fast, int max_w, int max_h, int max_batch,
+                  int device, sd_orb** out) {
+  SD_REQUIRE(out != nullptr, SD_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  SD_REQUIRE(nfeatures > 0 && nlevels >= 1 && nlevels <= SD_MAX_LEVELS && scale_factor > 1.0f, SD_ERR_INVALID_ARG,
+             "bad extractor parameters");
+  SD_REQUIRE(max_w >= 1 && max_h >= 1 && max_w <= SD_MAX_DIM && max_h <= SD_MAX_DIM && max_batch >= 1, SD_ERR_INVALID_ARG,
+             "bad capacity parameters");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device visible: the HIP path is the only implementation (no CPU fallback)");
+    return SD_ERR_NO_DEVICE;
+  }
+  SD_REQUIRE(device >= 0 && device < ndev, SD_ERR_INVALID_ARG, "device index out of range");
+  SD_HIP_CHECK(hipSetDevice(device));
+  sd_orb* h = new sd_orb();
+  h->nfeatures = nfeatures;
+  h->scaleFactor = scale_factor;
+  h->nlevels = nlevels;
+  h->thFAST = th_fast;
+  h->max_w = max_w;
+  h->max_h = max_h;
+  h->max_batch = max_batch;
+  h->device = device;
+  plan_tables(nfeatures, scale_factor, nlevels, h->hp);
+  int nsel = 0;
+  for (int q : h->hp.quota) nsel += q;
+  const size_t cap = std::max(nsel, 1);
+  hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&h->d_plan, sizeof(OrbPlan));
+  if (e == hipSuccess) e = hipMalloc(&h->d_img, (size_t)max_w * max_h * max_batch);
+  if (e == hipSuccess) e = hipMalloc(&h->d_kps, cap * max_batch * sizeof(sd_keypoint));
+  if (e == hipSuccess) e = hipMalloc(&h->d_desc, cap * max_batch * 32);
+  if (e == hipSuccess) e = hipMalloc(&h->d_nout, (size_t)max_batch * 4);
+  for (int i = 0; i <= ST_COUNT && e == hipSuccess; i++) e = hipEventCreate(&h->ev[i]);
+  if (e != hipSuccess) {
+    set_error(std::string("sd_orb_create: ") + hipGetErrorString(e));
+    sd_orb_destroy(h);
+    return SD_ERR_HIP;
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return SD_OK;
+}
+
+void sd_orb_destroy(sd_orb* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  free_geom(h);
+  void* ptrs[] = {h->d_plan, h->d_img, h->d_kps, h->d_desc, h->d_nout};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (int i = 0; i <= ST_COUNT; i++)
+    if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+int sd_orb_levels(const sd_orb* h) { return h ? h->nlevels : 0; }
+
+// Host-only (no GPU needed): geometry the extractor would use for a w x h frame.
+int sd_orb_plan_info(int nfeatures, float scale_factor, int nlevels, int th_fast, int w, int hgt, int32_t* level_info,
+                     int32_t* cell_zones, int cell_cap, int32_t* n_cells, uint64_t* bytes_per_frame) {
+  SD_REQUIRE(level_info && n_cells, SD_ERR_INVALID_ARG, "NULL argument");
+  SD_REQUIRE(nfeatures > 0 && nlevels >= 1 && nlevels <= SD_MAX_LEVELS && scale_factor > 1.0f, SD_ERR_INVALID_ARG,
+             "bad extractor parameters");
+  HostPlan hp;
+  plan_tables(nfeatures, scale_factor, nlevels, hp);
+  const char* why = "";
+  if (!plan_geometry(nfeatures, nlevels, th_fast, w, hgt, hp, &why)) {
+    set_error(std::string("unsupported geometry: ") + why);
+    return SD_ERR_INVALID_ARG;
+  }
+  for (int l = 0; l < nlevels; l++) {
+    const LevelGeom& L = hp.plan.lv[l];
+    int32_t* o = level_info + 8 * l;
+    o[0] = L.w; o[1] = L.h; o[2] = L.quota; o[3] = L.cols; o[4] = L.rows; o[5] = L.cellW; o[6] = L.cellH; o[7] = L.nfeaturesCell;
+  }
+  *n_cells = hp.plan.ncells;
+  if (cell_zones) {
+    SD_REQUIRE(cell_cap >= hp.plan.ncells, SD_ERR_CAPACITY, "cell_cap too small");
+    for (int c = 0; c < hp.plan.ncells; c++) {
+      const CellGeom& C = hp.cells[c];
+      int32_t* o = cell_zones + 6 * c;
+      o[0] = C.level; o[1] = C.zx0; o[2] = C.zy0; o[3] = C.zw; o[4] = C.zh; o[5] = C.evaluated;
+    }
+  }
+  if (bytes_per_frame) *bytes_per_frame = hp.plan.pyr_frame_bytes * 2 + (uint64_t)hp.plan.cand_per_frame * 8;
+  return SD_OK;
+}
+
+int sd_orb_scale_tables(const sd_orb* h, float* sf, float* inv_sf, float* sigma2, float* inv_sigma2) {
+  SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  for (int i = 0; i < h->nlevels; i++) {
+    if (sf) sf[i] = h->hp.sf[i];
+    if (inv_sf) inv_sf[i] = h->hp.inv_sf[i];
+    if (sigma2) sigma2[i] = h->hp.sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = h->hp.inv_sigma2[i];
+  }
+  return SD_OK;
+}
+
+int sd_orb_features_per_level(const sd_orb* h, int32_t* quota) {
+  SD_REQUIRE(h && quota, SD_ERR_INVALID_ARG, "NULL argument");
+  for (int i = 0; i < h->nlevels; i++) quota[i] = h->hp.quota[i];
+  return SD_OK;
+}
+
+int sd_orb_extract_batch_device(sd_orb* h, const void* d_imgs, int n_frames, int w, int hgt, int stride,
+                                size_t frame_stride) {
+  SD_REQUIRE(h && d_imgs, SD_ERR_INVALID_ARG, "NULL argument");
+  SD_REQUIRE(n_frames >= 1 && n_frames <= h->max_batch, SD_ERR_CAPACITY, "n_frames exceeds max_batch");
+  SD_REQUIRE(w >= 1 && hgt >= 1 && stride >= w && frame_stride >= (size_t)stride * (hgt - 1) + w, SD_ERR_INVALID_ARG,
+             "bad image shape/stride");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  int rc = ensure_geometry(h, w, hgt);
+  if (rc != SD_OK) return rc;
+  return launch_pipeline(h, (const uint8_t*)d_imgs, n_frames, stride, frame_stride);
+}
+
+int sd_orb_download(sd_orb* h, int frame0, int n_frames, sd_keypoint* kps_out, uint8_t* desc_out, int cap_per_frame,
+                    int32_t* n_out) {
+  SD_REQUIRE(h && n_out, SD_ERR_INVALID_ARG, "NULL argument");
+  SD_REQUIRE(frame0 >= 0 && n_frames >= 1 && frame0 + n_frames <= h->last_frames, SD_ERR_INVALID_ARG,
+             "frame range outside the last batch");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  const int cap = std::max(h->hp.plan.nsel, 1);
+  SD_HIP_CHECK(hipMemcpyAsync(n_out, h->d_nout + frame0, (size_t)n_frames * 4, hipMemcpyDeviceToHost, h->stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  for (int f = 0; f < n_frames; f++) {
+    int n = n_out[f];
+    SD_REQUIRE(n <= cap_per_frame || (!kps_out && !desc_out), SD_ERR_CAPACITY, "cap_per_frame smaller than keypoint count");
+    if (n <= 0) continue;
+    if (kps_out)
+      SD_HIP_CHECK(hipMemcpyAsync(kps_out + (size_t)f * cap_per_frame, h->d_kps + (size_t)(frame0 + f) * cap,
+                                  (size_t)n * sizeof(sd_keypoint), hipMemcpyDeviceToHost, h->stream));
+    if (desc_out)
+      SD_HIP_CHECK(hipMemcpyAsync(desc_out + (size_t)f * cap_per_frame * 32, h->d_desc + (size_t)(frame0 + f) * cap * 32,
+                                  (size_t)n * 32, hipMemcpyDeviceToHost, h->stream));
+  }
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SD_OK;
+}
+
+int sd_orb_extract_batch(sd_orb* h, const uint8_t* imgs, int n_frames, int w, int hgt, int stride, size_t frame_stride,
+                         sd_keypoint* kps_out, uint8_t* desc_out, int cap_per_frame, int32_t* n_out) {
+  SD_REQUIRE(h && n_out, SD_ERR_INVALID_ARG, "NULL argument");
+  if (w <= 0 || hgt <= 0 || !imgs) {   // _image.empty(): return silently (src/ORBextractor.cc:622-623)
+    for (int f = 0; f < n_frames; f++) n_out[f] = 0;
+    return SD_OK;
+  }
+  SD_REQUIRE(n_frames >= 1 && n_frames <= h->max_batch, SD_ERR_CAPACITY, "n_frames exceeds max_batch");
+  SD_REQUIRE(w <= h->max_w && hgt <= h->max_h, SD_ERR_CAPACITY, "frame larger than the handle's max_w x max_h");
+  SD_REQUIRE(stride >= w, SD_ERR_INVALID_ARG, "stride < width");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  // pack rows tightly into the staging buffer
+  SD_HIP_CHECK(hipMemcpy2DAsync(h->d_img, w, imgs, stride, w, (size_t)hgt, hipMemcpyHostToDevice, h->stream));
+  for (int f = 1; f < n_frames; f++)
+    SD_HIP_CHECK(hipMemcpy2DAsync(h->d_img + (size_t)f * w * hgt, w, imgs + (size_t)f * frame_stride, stride, w,
+                                  (size_t)hgt, hipMemcpyHostToDevice, h->stream));
+  int rc = sd_orb_extract_batch_device(h, h->d_img, n_frames, w, hgt, w, (size_t)w * hgt);
+  if (rc != SD_OK) return rc;
+  return sd_orb_download(h, 0, n_frames, kps_out, desc_out, cap_per_frame, n_out);
+}
+
+int sd_orb_extract(sd_orb* h, const uint8_t* img, int w, int hgt, int stride, sd_keypoint* kps_out, uint8_t* desc_out,
+                   int cap, int* n_out) {
+  SD_REQUIRE(n_out, SD_ERR_INVALID_ARG, "n_out is NULL");
+  int32_t n = 0;
+  int rc = sd_orb_extract_batch(h, img, 1, w, hgt, stride, (size_t)stride * (hgt > 0 ? hgt : 0), kps_out, desc_out, cap, &n);
+  *n_out = n;
+  return rc;
+}
+
+int sd_orb_level_info(const sd_orb* h, int level, int* w, int* hgt) {
+  SD_REQUIRE(h && h->have_geom && level >= 0 && level < h->nlevels, SD_ERR_INVALID_ARG, "no geometry / bad level");
+  if (w) *w = h->hp.plan.lv[level].w;
+  if (hgt) *hgt = h->hp.plan.lv[level].h;
+  return SD_OK;
+}
+
+static int copy_level(sd_orb* h, const uint8_t* base, int frame, int level, int padded, uint8_t* out, int out_stride) {
+  SD_REQUIRE(h && out && h->have_geom && level >= 0 && level < h->nlevels && frame >= 0 && frame < h->last_frames,
+             SD_ERR_INVALID_ARG, "bad frame/level");
+  const LevelGeom& L = h->hp.plan.lv[level];
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  const uint8_t* src = base + (size_t)frame * h->hp.plan.pyr_frame_bytes + L.off;
+  int wc = L.w, hc = L.h;
+  if (padded) {
+    wc += 2 * SD_EDGE;
+    hc += 2 * SD_EDGE;
+  } else {
+    src += (size_t)SD_EDGE * L.pstride + SD_EDGE;
+  }
+  SD_REQUIRE(out_stride >= wc, SD_ERR_INVALID_ARG, "out_stride too small");
+  SD_HIP_CHECK(hipMemcpy2DAsync(out, out_stride, src, L.pstride, wc, hc, hipMemcpyDeviceToHost, h->stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SD_OK;
+}
+
+int sd_orb_level_copy(sd_orb* h, int frame, int level, int padded, uint8_t* out, int out_stride) {
+  SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  return copy_level(h, h->d_pyr, frame, level, padded, out, out_stride);
+}
+
+int sd_orb_debug_blurred(sd_orb* h, int frame, int level, uint8_t* out, int out_stride) {
+  SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  return copy_level(h, h->d_blur, frame, level, 0, out, out_stride);
+}
+
+int sd_orb_debug_cell_counts(sd_orb* h, int frame, int level, int32_t* out, int cap, int* n_cells) {
+  SD_REQUIRE(h && out && n_cells && h->have_geom && level >= 0 && level < h->nlevels && frame >= 0 && frame < h->last_frames,
+             SD_ERR_INVALID_ARG, "bad frame/level");
+  const LevelGeom& L = h->hp.plan.lv[level];
+  *n_cells = L.ncells;
+  SD_REQUIRE(cap >= L.ncells, SD_ERR_CAPACITY, "cap too small");
+  if (L.ncells == 0) return SD_OK;
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipMemcpyAsync(out, h->d_cell_count + (size_t)frame * h->hp.plan.ncells + L.cell0, (size_t)L.ncells * 4,
+                              hipMemcpyDeviceToHost, h->stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SD_OK;
+}
+
+int sd_orb_debug_level_keys(sd_orb* h, int frame, int level, uint32_t* keys_out, int cap, int* n) {
+  SD_REQUIRE(h && keys_out && n && h->have_geom && level >= 0 && level < h->nlevels && frame >= 0 && frame < h->last_frames,
+             SD_ERR_INVALID_ARG, "bad frame/level");
+  const LevelGeom& L = h->hp.plan.lv[level];
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  int32_t cnt = 0;
+  SD_HIP_CHECK(hipMemcpyAsync(&cnt, h->d_sel_count + (size_t)frame * h->nlevels + level, 4, hipMemcpyDeviceToHost, h->stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  *n = cnt;
+  SD_REQUIRE(cap >= cnt, SD_ERR_CAPACITY, "cap too small");
+  if (cnt > 0) {
+    SD_HIP_CHECK(hipMemcpyAsync(keys_out, h->d_sel + (size_t)frame * h->hp.plan.nsel + L.sel_off, (size_t)cnt * 4,
+                                hipMemcpyDeviceToHost, h->stream));
+    SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+  return SD_OK;
+}
+
+int sd_orb_set_stream(sd_orb* h, void* hip_stream) {
+  SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return SD_OK;
+}
+
+int sd_orb_sync(sd_orb* h) {
+  SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SD_OK;
+}
+
+int sd_orb_set_profiling(sd_orb* h, int on) {
+  SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  h->profiling = on != 0;
+  return SD_OK;
+}
+
+int sd_orb_num_stages(void) { return ST_COUNT; }
+const char* sd_orb_stage_name(int stage) { return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : ""; }
+
+int sd_orb_stage_ms(sd_orb* h, float* ms_out, int cap) {
+  SD_REQUIRE(h && ms_out && cap >= ST_COUNT, SD_ERR_INVALID_ARG, "bad arguments");
+  SD_REQUIRE(h->profiling, SD_ERR_INVALID_ARG, "profiling is off");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipEventSynchronize(h->ev[ST_COUNT]));
+  for (int i = 0; i < ST_COUNT; i++) {
+    float ms = 0;
+    SD_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    ms_out[i] = ms;
+  }
+  return SD_OK;
+}
+
+int sd_orb_stage_bytes(const sd_orb* h, double* bytes_out, int cap) {
+  SD_REQUIRE(h && bytes_out && cap >= ST_COUNT && h->have_geom, SD_ERR_INVALID_ARG, "bad arguments / no geometry yet");
+  for (int i = 0; i < ST_COUNT; i++) bytes_out[i] = h->hp.stage_bytes[i];
+  return SD_OK;
+}
+
+int sd_dev_alloc(size_t bytes, void** out) {
+  SD_REQUIRE(out, SD_ERR_INVALID_ARG, "out is NULL");
+  SD_HIP_CHECK(hipMalloc(out, bytes));
+  return SD_OK;
+}
+int sd_dev_free(void* p) {
+  SD_HIP_CHECK(hipFree(p));
+  return SD_OK;
+}
+int sd_dev_upload(void* dst, const void* src, size_t bytes) {
+  SD_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return SD_OK;
+}
+int sd_dev_download(void* dst, const void* src, size_t bytes) {
+  SD_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return SD_OK;
+}
+
+// ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1459-1473): 256-bit Hamming distance
+int sd_hamming(const uint8_t* a32, const uint8_t* b32) {
+  int dist = 0;
+  for (int i = 0; i < 4; i++) {
+    uint64_t x, y;
+    memcpy(&x, a32 + 8 * i, 8);
+    memcpy(&y, b32 + 8 * i, 8);
+    dist += __builtin_popcountll(x ^ y);
+  }
+  return dist;
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// See orb_plan.h.  Pure host code (no HIP).
+#include "orb_plan.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace sd {
+
+static inline int cv_round(float v) { return (int)lrintf(v); }
+static inline int cv_round(double v) { return (int)lrint(v); }
+static inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+static inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// reference src/ORBextractor.cc:406-434 (note: the member scaleFactor is a double holding the
+// float ctor argument, src/ORBextractor.h:38,78 -- the products below promote accordingly)
+void plan_tables(int nfeatures, float scaleFactorArg, int nlevels, HostPlan& hp) {
+  const double scaleFactor = scaleFactorArg;
+  hp.sf.assign(nlevels, 1.0f);
+  hp.sigma2.assign(nlevels, 1.0f);
+  for (int i = 1; i < nlevels; i++) {
+    hp.sf[i] = (float)(hp.sf[i - 1] * scaleFactor);
+    hp.sigma2[i] = hp.sf[i] * hp.sf[i];
+  }
+  hp.inv_sf.resize(nlevels);
+  hp.inv_sigma2.resize(nlevels);
+  for (int i = 0; i < nlevels; i++) {
+    hp.inv_sf[i] = 1.0f / hp.sf[i];
+    hp.inv_sigma2[i] = 1.0f / hp.sigma2[i];
+  }
+  hp.quota.assign(nlevels, 0);
+  float factor = (float)(1.0f / scaleFactor);
+  float nDesired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+  int sum = 0;
+  for (int l = 0; l < nlevels - 1; l++) {
+    hp.quota[l] = cv_round(nDesired);
+    sum += hp.quota[l];
+    nDesired *= factor;
+  }
+  hp.quota[nlevels - 1] = std::max(nfeatures - sum, 0);
+}
+
+// cv::resize INTER_LINEAR coefficient tables (OpenCV 3.2 semantics)
+static void resize_tables(int sn, int dn, std::vector<int32_t>& ofs, std::vector<int32_t>& ab, bool clamp_x) {
+  double inv_scale = (double)dn / sn;
+  double scale = 1. / inv_scale;
+  ofs.resize(dn);
+  ab.resize(dn);
+  for (int d = 0; d < dn; d++) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = cv_floor(f);
+    f -= s;
+    if (clamp_x) {
+      if (s < 0) { f = 0; s = 0; }
+      if (s + 1 >= sn && s >= sn - 1) { f = 0; s = sn - 1; }
+    }
+    float c0 = 1.f - f, c1 = f;
+    int a0 = std::min(std::max(cv_round(c0 * 2048.f), -32768), 32767);
+    int a1 = std::min(std::max(cv_round(c1 * 2048.f), -32768), 32767);
+    ofs[d] = s;
+    ab[d] = (int32_t)((uint32_t)(uint16_t)(int16_t)a0 | ((uint32_t)(uint16_t)(int16_t)a1 << 16));
+  }
+}
+
+bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPlan& hp, const char** why) {
+  (void)nfeatures;
+  if (nlevels < 1 || nlevels > SD_MAX_LEVELS) { *why = "nlevels out of range"; return false; }
+  if (w < 1 || h < 1 || w > SD_MAX_DIM || h > SD_MAX_DIM) { *why = "image size out of range (1..4095)"; return false; }
+  OrbPlan& P = hp.plan;
+  memset(&P, 0, sizeof(P));
+  P.nlevels = nlevels;
+  P.thFAST = std::min(std::max(thFAST, 0), 255);
+  P.w0 = w;
+  P.h0 = h;
+  hp.cells.clear();
+  hp.blur_tiles.clear();
+  hp.coef.clear();
+  hp.max_cells_per_level = 0;
+
+  size_t off = 0;
+  uint32_t cand = 0;
+  int sel = 0;
+  const float imageRatio = (float)w / h;   // src/ORBextractor.cc:469 (level 0 cols/rows)
+  size_t lds_max = 0;
+  double sum_px = 0, px0 = 0, px_last = 0;
+
+  for (int l = 0; l < nlevels; l++) {
+    LevelGeom& L = P.lv[l];
+    float scale = hp.inv_sf[l];
+    L.w = cv_round((float)w * scale);   // src/ORBextractor.cc:683
+    L.h = cv_round((float)h * scale);
+    if (L.w < 1 || L.h < 1) { *why = "pyramid level collapses to zero size"; return false; }
+    L.pstride = (int)up((size_t)L.w + 2 * SD_EDGE, 64);
+    L.prows = L.h + 2 * SD_EDGE;
+    L.off = (uint32_t)off;
+    off += up((size_t)L.pstride * L.prows, 256);
+    L.quota = hp.quota[l];
+    L.scale = hp.sf[l];
+    L.kpsize = (float)(int)(31 * hp.sf[l]);   // const int scaledPatchSize = PATCH_SIZE*mvScaleFactor[level]
+    L.sel_off = sel;
+    sel += L.quota;
+    sum_px += (double)L.w * L.h;
+    if (l == 0) px0 = (double)L.w * L.h;
+    px_last = (double)L.w * L.h;
+
+    // resize tables (level l from level l-1)
+    L.area2x2 = 0;
+    L.cx = L.cy = 0;
+    if (l > 0) {
+      const LevelGeom& S = P.lv[l - 1];
+      double sx = 1. / ((double)L.w / S.w), sy = 1. / ((double)L.h / S.h);
+      int isx = cv_round(sx), isy = cv_round(sy);
+      bool fast = std::fabs(sx - isx) < DBL_EPSILON && std::fabs(sy - isy) < DBL_EPSILON;
+      if (fast && isx == 2 && isy == 2) {
+        L.area2x2 = 1;
+      } else {
+        std::vector<int32_t> xo, xa, yo, yb;
+        resize_tables(S.w, L.w, xo, xa, true);
+        resize_tables(S.h, L.h, yo, yb, false);
+        L.cx = (int)hp.coef.size();
+        hp.coef.insert(hp.coef.end(), xo.begin(), xo.end());
+        hp.coef.insert(hp.coef.end(), xa.begin(), xa.end());
+        L.cy = (int)hp.coef.size();
+        hp.coef.insert(hp.coef.end(), yo.begin(), yo.end());
+        hp.coef.insert(hp.coef.end(), yb.begin(), yb.end());
+      }
+    }
+
+    // grid (src/ORBextractor.cc:472-488)
+    const int nDesired = L.quota;
+    const int levelCols = (int)sqrtf((float)nDesired / (5 * imageRatio));
+    const int levelRows = (int)(imageRatio * levelCols);
+    L.cell0 = (int)hp.cells.size();
+    L.cand_off = cand;
+    L.cols = L.rows = L.ncells = 0;
+    L.cellW = L.cellH = L.nfeaturesCell = 0;
+    if (levelCols > 0 && levelRows > 0 && nDesired > 0) {
+      const int minBX = SD_EDGE, minBY = SD_EDGE, maxBX = L.w - SD_EDGE, maxBY = L.h - SD_EDGE;
+      const int W = maxBX - minBX, H = maxBY - minBY;
+      const int cellW = (int)ceilf((float)W / levelCols);
+      const int cellH = (int)ceilf((float)H / levelRows);
+      L.cols = levelCols;
+      L.rows = levelRows;
+      L.cellW = cellW;
+      L.cellH = cellH;
+      L.ncells = levelCols * levelRows;
+      L.nfeaturesCell = (int)ceilf((float)nDesired / L.ncells);
+      for (int i = 0; i < levelRows; i++) {
+        const int iniY = minBY + i * cellH - 3;
+        int hY = cellH + 6;
+        if (i == levelRows - 1) hY = maxBY + 3 - iniY;
+        for (int j = 0; j < levelCols; j++) {
+          const int iniX = minBX + j * cellW - 3;
+          int hX = cellW + 6;
+          if (j == levelCols - 1) hX = maxBX + 3 - iniX;
+          CellGeom c;
+          c.level = l;
+          // Cells the reference skips with `continue` (src/ORBextractor.cc:507-511,526-530) keep
+          // bNoMore=false / nTotal=0 and enter the quota loop differently from cells whose FAST
+          // call simply finds nothing, so the distinction is carried in `evaluated`.  A cell view
+          // outside the level image (cv::Mat::rowRange/colRange would throw; degenerate grids
+          // only) is treated as skipped, like the oracle does.
+          bool skip = (i == levelRows - 1 && hY <= 0) || (j == levelCols - 1 && hX <= 0) || iniX < 0 ||
+                      iniY < 0 || hX < 0 || hY < 0 || iniX + hX > L.w || iniY + hY > L.h;
+          bool ok = !skip && hX > 6 && hY > 6;   // FAST scans [3, dim-3) of the cell view
+          c.evaluated = skip ? 0 : 1;
+          c.zx0 = iniX + 3;
+          c.zy0 = iniY + 3;
+          c.zw = ok ? hX - 6 : 0;
+          c.zh = ok ? hY - 6 : 0;
+          c.cap = ok ? (uint32_t)(((c.zw + 1) / 2) * ((c.zh + 1) / 2)) : 0;
+          c.cand_off = cand;
+          cand += c.cap;
+          c.strip_rows = 0;
+          if (ok) {
+            int S = std::min(c.zh, std::max(1, 12288 / c.zw));
+            for (;;) {
+              size_t tp = up((size_t)c.zw + 6 + 3, 4), sp = up((size_t)c.zw + 2, 4);
+              size_t need = tp * (S + 2 + 6) + sp * (S + 2 + 2) + 64;
+              if (need <= 56 * 1024 || S == 1) { lds_max = std::max(lds_max, need); break; }
+              S = std::max(1, S / 2);
+            }
+            c.strip_rows = S;
+          }
+          hp.cells.push_back(c);
+        }
+      }
+    }
+    L.cand_cap = cand - L.cand_off;
+    hp.max_cells_per_level = std::max(hp.max_cells_per_level, L.ncells);
+
+    for (int ty = 0; ty < (L.h + 15) / 16; ty++)
+      for (int tx = 0; tx < (L.w + 63) / 64; tx++) hp.blur_tiles.push_back(BlurTile{l, tx, ty});
+  }
+  P.ncells = (int)hp.cells.size();
+  P.nsel = sel;
+  P.cand_per_frame = cand;
+  P.pyr_frame_bytes = off;
+  hp.fast_lds_bytes = lds_max;
+  if (hp.coef.empty()) hp.coef.push_back(0);
+
+  // algorithmic bytes per frame: each stage reads its input once, writes once
+  hp.stage_bytes[0] = (sum_px - px_last) + (sum_px - px0) + px0 * 2;  // pyramid (+ level-0 copy in/out)
+  hp.stage_bytes[1] = sum_px;                                         // FAST + NMS scan (read)
+  hp.stage_bytes[2] = (double)cand * 0 + (double)sel * 4;             // selection (keys; negligible)
+  hp.stage_bytes[3] = 2 * sum_px;                                     // blur read + write
+  hp.stage_bytes[4] = (double)sel * (749 + 961 + 28 + 32);            // orientation + rBRIEF gathers + outputs
+  return true;
+}
+
+}  // namespace sd

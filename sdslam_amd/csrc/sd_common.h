@@ -1,0 +1,34 @@
+// Shared host-side plumbing for libsdslam_hip.so (error reporting, HIP call checking).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/sdslam_hip.h"
+
+namespace sd {
+
+void set_error(const std::string& msg);
+
+#define SD_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      ::sd::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                      ":" + std::to_string(__LINE__) + ")");                            \
+      return SD_ERR_HIP;                                                                \
+    }                                                                                   \
+  } while (0)
+
+#define SD_REQUIRE(cond, code, msg) \
+  do {                              \
+    if (!(cond)) {                  \
+      ::sd::set_error(msg);         \
+      return (code);                \
+    }                               \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace sd

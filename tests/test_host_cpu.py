@@ -1,0 +1,132 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, host-side
+planning matches the oracle's geometry, and the two exactness-critical device helpers
+(libstdc++ introselect replay, glibc sinf/cosf restatement) agree with the host's real
+implementations when compiled for the CPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import sdslam_amd
+    from sdslam_amd import build
+    build.build()          # hipcc cross-compiles gfx950 without a GPU
+    return sdslam_amd
+
+
+def test_library_exports_every_declared_symbol(sd):
+    hdr = open(os.path.join(ROOT, "include", "sdslam_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(sd_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) > 20
+    L = sd.lib()
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, f"declared in include/sdslam_hip.h but not exported: {missing}"
+    assert b"gfx950" in L.sd_version()
+
+
+def test_no_gpu_means_loud_failure_not_fallback(sd):
+    if sd.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(sd.SdError) as ei:
+        sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 1)
+    assert "no HIP device" in str(ei.value) or ei.value.code in (2, 4)
+
+
+def test_product_package_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sdslam_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_hamming_matches_popcount(sd):
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        a = rng.integers(0, 256, 32).astype(np.uint8)
+        b = rng.integers(0, 256, 32).astype(np.uint8)
+        assert sd.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
+    z, o = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert sd.hamming(z, z) == 0 and sd.hamming(z, o) == 256
+    one = z.copy()
+    one[17] = 0x10
+    assert sd.hamming(z, one) == 1
+
+
+@pytest.mark.parametrize("cfg,size", [((1000, 1.2, 8, 20), (640, 480)), ((1000, 2.0, 5, 20), (640, 480)),
+                                      ((1000, 1.2, 8, 20), (1280, 720)), ((2000, 1.2, 8, 20), (752, 480))])
+def test_plan_matches_oracle_geometry(sd, oracle, cfg, size):
+    from sdslam_amd.synth import make_image
+    w, h = size
+    info = sd.plan_info(*cfg, w, h)
+    ora = oracle.OrbOracle(*cfg)
+    img = make_image(1, w, h)
+    ora.extract(img)
+    t = ora.tables()
+    for l in range(cfg[2]):
+        lw, lh = ora.level(l).shape[::-1]
+        assert (info["levels"][l, 0], info["levels"][l, 1]) == (lw, lh)
+        assert info["levels"][l, 2] == t["quota"][l]
+        # one count per grid cell in the oracle == cols*rows of the plan
+        assert len(ora.cell_totals(l)) == info["levels"][l, 3] * info["levels"][l, 4]
+    # detection zones tile [19, w-19) x [19, h-19) without overlap on sane grids
+    cells = info["cells"]
+    for l in range(cfg[2]):
+        z = cells[(cells[:, 0] == l) & (cells[:, 3] > 0)]
+        if len(z) == 0:
+            continue
+        lw, lh = info["levels"][l, 0], info["levels"][l, 1]
+        cover = np.zeros((lh, lw), np.int32)
+        for _, x0, y0, zw, zh, _ in z:
+            cover[y0:y0 + zh, x0:x0 + zw] += 1
+        assert cover.max() == 1
+        assert cover[19:lh - 19, 19:lw - 19].min() == 1
+        assert cover.sum() == (lw - 38) * (lh - 38)
+
+
+def test_known_level_tables(sd):
+    info = sd.plan_info(1000, 1.2, 8, 20, 640, 480)
+    assert info["levels"][:, :3].tolist() == [[640, 480, 217], [533, 400, 181], [444, 333, 151], [370, 278, 126],
+                                              [309, 231, 105], [257, 193, 87], [214, 161, 73], [179, 134, 60]]
+    assert info["levels"][0, 3:].tolist() == [5, 6, 121, 74, 8]
+    info = sd.plan_info(1000, 2.0, 5, 20, 640, 480)
+    assert info["levels"][:, :3].tolist() == [[640, 480, 516], [320, 240, 258], [160, 120, 129], [80, 60, 65],
+                                              [40, 30, 32]]
+    # P5 level 4 (40x30): degenerate grid, no detection zone at all
+    assert (info["cells"][info["cells"][:, 0] == 4][:, 3] == 0).all()
+
+
+def _native(name, extra=()):
+    out = os.path.join("/tmp", f"sd_{name}.so")
+    src = os.path.join(ROOT, "tests", "native", f"{name}.cc")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", *extra, src, "-o", out, "-lm"])
+    return C.CDLL(out)
+
+
+def test_introselect_replays_libstdcxx_nth_element():
+    L = _native("introselect_check")
+    L.introselect_selftest.restype = C.c_long
+    L.introselect_heap_cases.restype = C.c_long
+    assert L.introselect_selftest(1, 4000, 3000, 40) == 0
+    assert L.introselect_selftest(2, 60000, 40, 6) == 0
+    heap_calls = C.c_long()
+    assert L.introselect_heap_cases(3, 60000, C.byref(heap_calls)) == 0
+    assert heap_calls.value > 100      # the depth-limit / heap_select fallback really was exercised
+
+
+def test_sincosf_restatement_matches_host_libm_sampled():
+    # exhaustive run (1.09e9 floats, 0 mismatches): tools/check_sincosf.cc; here every 257th float
+    exe = "/tmp/sd_check_sincosf"
+    subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", os.path.join(ROOT, "tools", "check_sincosf.cc"),
+                           "-o", exe, "-lm"])
+    out = subprocess.run([exe, "257"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "sin mismatches 0, cos mismatches 0" in out.stdout
