@@ -92,8 +92,9 @@ int sd_orb_debug_level_keys(sd_orb* h, int frame, int level, uint32_t* keys_out,
 
 /* Stream / timing plumbing (bench + rocprof).  sd_orb_set_stream: run on a caller-owned
  * hipStream_t (NULL restores the handle's own stream).  With profiling on, every extract call
- * brackets each stage with HIP events on the launch stream; sd_orb_stage_ms returns the
- * elapsed ms of the last call per stage (names from sd_orb_stage_name). */
+ * brackets each stage with HIP events on the launch stream; sd_orb_stage_ms returns the mean
+ * elapsed ms per stage over the calls made since profiling was switched on (last 128 at most;
+ * names from sd_orb_stage_name). */
 int sd_orb_set_stream(sd_orb* h, void* hip_stream);
 int sd_orb_sync(sd_orb* h);
 int sd_orb_set_profiling(sd_orb* h, int on);

@@ -654,8 +654,10 @@ struct sd_orb {
   int32_t* d_nout = nullptr;
   size_t cap_pyr = 0, cap_cand = 0, cap_cells = 0, cap_tiles = 0, cap_coef = 0;
   bool profiling = false;
-  hipEvent_t ev[ST_COUNT + 1] = {};
-  float stage_ms[ST_COUNT] = {};
+  // ring of per-call stage events: the bench reads mean stage times over its whole timed region
+  static const int kRing = 128;
+  hipEvent_t ev[kRing][ST_COUNT + 1] = {};
+  int ev_calls = 0;   // calls recorded since profiling was (re-)enabled
 };
 
 static int free_geom(sd_orb* h) {
@@ -713,29 +715,31 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   const OrbPlan& P = hp.plan;
   hipStream_t s = h->stream;
   const bool prof = h->profiling;
-  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[0], s));
+  hipEvent_t* ev = h->ev[h->ev_calls % sd_orb::kRing];
+  if (prof) SD_HIP_CHECK(hipEventRecord(ev[0], s));
   for (int l = 0; l < P.nlevels; l++) {
     const LevelGeom& L = P.lv[l];
     dim3 grid((L.pstride + 255) / 256, (L.prows + 3) / 4, n), block(64, 4, 1);
     hipLaunchKernelGGL(k_pyr_level, grid, block, 0, s, h->d_plan, l, d_imgs, stride, frame_stride, h->d_pyr, h->d_coef);
   }
-  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[1], s));
+  if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], s));
   if (P.ncells > 0) {
     hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, n), dim3(256), hp.fast_lds_bytes, s, h->d_plan, h->d_cells,
                        h->d_pyr, h->d_cand, h->d_cell_count);
   }
-  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[2], s));
+  if (prof) SD_HIP_CHECK(hipEventRecord(ev[2], s));
   hipLaunchKernelGGL(k_select_level, dim3(P.nlevels, n), dim3(256), 0, s, h->d_plan, h->d_cells, h->d_cand,
                      h->d_cell_count, h->d_scratch, h->d_sel, h->d_sel_count);
-  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[3], s));
+  if (prof) SD_HIP_CHECK(hipEventRecord(ev[3], s));
   hipLaunchKernelGGL(k_blur, dim3((unsigned)hp.blur_tiles.size(), n), dim3(256), 0, s, h->d_plan, h->d_tiles, h->d_pyr,
                      h->d_blur, h->d_sel_count);
-  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[4], s));
+  if (prof) SD_HIP_CHECK(hipEventRecord(ev[4], s));
   const int cap = std::max(P.nsel, 1);
   hipLaunchKernelGGL(k_orient_desc, dim3((cap + 3) / 4, n), dim3(256), 0, s, h->d_plan, h->d_pyr, h->d_blur, h->d_sel,
                      h->d_sel_count, h->d_kps, h->d_desc, h->d_nout, cap);
-  if (prof) SD_HIP_CHECK(hipEventRecord(h->ev[5], s));
+  if (prof) SD_HIP_CHECK(hipEventRecord(ev[5], s));
   SD_HIP_CHECK(hipGetLastError());
+  if (prof) h->ev_calls++;
   h->last_frames = n;
   return SD_OK;
 }
@@ -785,7 +789,8 @@ int sd_orb_create(int nfeatures, float scale_factor, int nlevels, int th_fast, i
   if (e == hipSuccess) e = hipMalloc(&h->d_kps, cap * max_batch * sizeof(sd_keypoint));
   if (e == hipSuccess) e = hipMalloc(&h->d_desc, cap * max_batch * 32);
   if (e == hipSuccess) e = hipMalloc(&h->d_nout, (size_t)max_batch * 4);
-  for (int i = 0; i <= ST_COUNT && e == hipSuccess; i++) e = hipEventCreate(&h->ev[i]);
+  for (int r = 0; r < sd_orb::kRing && e == hipSuccess; r++)
+    for (int i = 0; i <= ST_COUNT && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
   if (e != hipSuccess) {
     set_error(std::string("sd_orb_create: ") + hipGetErrorString(e));
     sd_orb_destroy(h);
@@ -804,8 +809,9 @@ void sd_orb_destroy(sd_orb* h) {
   void* ptrs[] = {h->d_plan, h->d_img, h->d_kps, h->d_desc, h->d_nout};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  for (int i = 0; i <= ST_COUNT; i++)
-    if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  for (int r = 0; r < sd_orb::kRing; r++)
+    for (int i = 0; i <= ST_COUNT; i++)
+      if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -1012,6 +1018,7 @@ int sd_orb_sync(sd_orb* h) {
 int sd_orb_set_profiling(sd_orb* h, int on) {
   SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
   h->profiling = on != 0;
+  h->ev_calls = 0;
   return SD_OK;
 }
 
@@ -1020,13 +1027,18 @@ const char* sd_orb_stage_name(int stage) { return (stage >= 0 && stage < ST_COUN
 
 int sd_orb_stage_ms(sd_orb* h, float* ms_out, int cap) {
   SD_REQUIRE(h && ms_out && cap >= ST_COUNT, SD_ERR_INVALID_ARG, "bad arguments");
-  SD_REQUIRE(h->profiling, SD_ERR_INVALID_ARG, "profiling is off");
+  SD_REQUIRE(h->profiling && h->ev_calls > 0, SD_ERR_INVALID_ARG, "profiling is off or no call recorded");
   SD_HIP_CHECK(hipSetDevice(h->device));
-  SD_HIP_CHECK(hipEventSynchronize(h->ev[ST_COUNT]));
-  for (int i = 0; i < ST_COUNT; i++) {
-    float ms = 0;
-    SD_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-    ms_out[i] = ms;
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  const int n = std::min(h->ev_calls, (int)sd_orb::kRing);
+  for (int i = 0; i < ST_COUNT; i++) ms_out[i] = 0.f;
+  for (int r = 0; r < n; r++) {
+    const int slot = (h->ev_calls - 1 - r) % sd_orb::kRing;
+    for (int i = 0; i < ST_COUNT; i++) {
+      float ms = 0;
+      SD_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[slot][i], h->ev[slot][i + 1]));
+      ms_out[i] += ms / n;
+    }
   }
   return SD_OK;
 }
