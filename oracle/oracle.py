@@ -162,3 +162,193 @@ def retain_best(kps, n_points):
     buf = np.ascontiguousarray(kps.copy())
     n = lib().orc_retain_best(_p(buf), len(buf), n_points)
     return buf[:n].copy()
+
+
+# ---- ImageAlign / matcher / PnP oracles -------------------------------------------------
+def _cm(T):
+    """4x4 numpy (row-major math) -> 16 doubles column-major (Eigen::Matrix4d::data())."""
+    return np.ascontiguousarray(np.asarray(T, np.float64).T).ravel().copy()
+
+
+def _from_cm(v):
+    return np.asarray(v, np.float64).reshape(4, 4).T.copy()
+
+
+def align(cur_levels, ref_levels, inv_sf, sf, Xw, T_ref, T_cur_init, K, mode=0):
+    """ImageAlign::ComputePose on explicit pyramids (lists of 2-D uint8 arrays, index = level).
+    Returns dict(ok, T (4x4), error, iters (per level), chi2)."""
+    L = lib()
+    n = len(cur_levels)
+    cur = [np.ascontiguousarray(a, np.uint8) for a in cur_levels]
+    ref = [np.ascontiguousarray(a, np.uint8) for a in ref_levels]
+    PtrArr = C.c_void_p * n
+    cp = PtrArr(*[a.ctypes.data for a in cur])
+    rp = PtrArr(*[a.ctypes.data for a in ref])
+    w = np.array([a.shape[1] for a in cur], np.int32)
+    h = np.array([a.shape[0] for a in cur], np.int32)
+    sc = np.array([a.strides[0] for a in cur], np.int32)
+    sr = np.array([a.strides[0] for a in ref], np.int32)
+    inv_sf = np.ascontiguousarray(inv_sf, np.float32)
+    sf = np.ascontiguousarray(sf, np.float32)
+    Xw = np.ascontiguousarray(Xw, np.float64)
+    Tr = _cm(T_ref)
+    Tc = _cm(T_cur_init)
+    err = C.c_double()
+    chi2 = C.c_double()
+    iters = np.zeros(n, np.int32)
+    L.orc_align.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                            C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    ok = L.orc_align(n, cp, rp, _p(w), _p(h), _p(sc), _p(sr), _p(inv_sf), _p(sf), _p(Xw), len(Xw), _p(Tr), _p(Tc),
+                     float(K[0]), float(K[1]), float(K[2]), float(K[3]), mode, C.byref(err), _p(iters), C.byref(chi2))
+    return dict(ok=bool(ok), T=_from_cm(Tc), error=err.value, iters=iters, chi2=chi2.value)
+
+
+def se3_exp(update6):
+    out = np.zeros(16)
+    u = np.ascontiguousarray(update6, np.float64)
+    lib().orc_se3_exp(_p(u), _p(out))
+    return _from_cm(out)
+
+
+def ldlt_solve6(H, b):
+    H = np.ascontiguousarray(H, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros(6)
+    lib().orc_ldlt_solve6(_p(H), _p(b), _p(x))
+    return x
+
+
+def search_by_projection(kps_un, desc, sf, bounds, K, T_cw, T_lw, last, th=8.0, mono=True, check_ori=True,
+                         u_right=None, mbf=0.0, mb=0.0, cur_match=None):
+    """ORBmatcher::SearchByProjection(Frame&, const Frame&).  `last` = dict(valid, Xw, desc, octave,
+    angle, obs).  Returns (nmatches, cur_match[N])."""
+    L = lib()
+    kps_un = np.ascontiguousarray(kps_un)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    N = len(kps_un)
+    cm = np.full(N, -1, np.int32) if cur_match is None else np.ascontiguousarray(cur_match, np.int32).copy()
+    sf = np.ascontiguousarray(sf, np.float32)
+    Tc, Tl = _cm(T_cw), _cm(T_lw)
+    valid = np.ascontiguousarray(last["valid"], np.uint8)
+    Xw = np.ascontiguousarray(last["Xw"], np.float64)
+    md = np.ascontiguousarray(last["desc"], np.uint8)
+    oc = np.ascontiguousarray(last["octave"], np.int32)
+    an = np.ascontiguousarray(last["angle"], np.float32)
+    ob = np.ascontiguousarray(last["obs"], np.int32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    L.orc_search_by_projection.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_float] * 10 + \
+        [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int, C.c_void_p]
+    n = L.orc_search_by_projection(N, _p(kps_un), _p(desc), _p(ur) if ur is not None else None, _p(sf),
+                                   float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]),
+                                   float(K[0]), float(K[1]), float(K[2]), float(K[3]), float(mbf), float(mb),
+                                   _p(Tc), _p(Tl), len(valid), _p(valid), _p(Xw), _p(md), _p(oc), _p(an), _p(ob),
+                                   float(th), int(mono), int(check_ori), _p(cm))
+    return n, cm
+
+
+def features_in_area(kps_un, bounds, x, y, r, min_level=-1, max_level=-1):
+    L = lib()
+    kps_un = np.ascontiguousarray(kps_un)
+    out = np.zeros(len(kps_un) + 1, np.int32)
+    L.orc_features_in_area.argtypes = [C.c_int, C.c_void_p] + [C.c_float] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = L.orc_features_in_area(len(kps_un), _p(kps_un), *[float(b) for b in bounds], float(x), float(y), float(r),
+                               min_level, max_level, _p(out), len(out))
+    return out[:n].copy()
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().orc_descriptor_distance(_p(a), _p(b)))
+
+
+class PnPOracle:
+    """SD_SLAM::PnPsolver(F, vpMapPointMatches) + SetRansacParameters + iterate."""
+
+    def __init__(self, valid, kp_xy, kp_octave, level_sigma2, Xw, K):
+        self.L = lib()
+        self.n = len(valid)
+        valid = np.ascontiguousarray(valid, np.uint8)
+        kp_xy = np.ascontiguousarray(kp_xy, np.float32)
+        kp_octave = np.ascontiguousarray(kp_octave, np.int32)
+        level_sigma2 = np.ascontiguousarray(level_sigma2, np.float32)
+        Xw = np.ascontiguousarray(Xw, np.float64)
+        self.L.orc_pnp_create.restype = C.c_void_p
+        self.L.orc_pnp_create.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_float] * 4
+        self.h = C.c_void_p(self.L.orc_pnp_create(self.n, _p(valid), _p(kp_xy), _p(kp_octave), _p(level_sigma2), _p(Xw),
+                                                  float(K[0]), float(K[1]), float(K[2]), float(K[3])))
+        self.L.orc_pnp_destroy.argtypes = [C.c_void_p]
+        self.L.orc_pnp_set_ransac.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+        self.L.orc_pnp_iterate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        self.L.orc_pnp_params.argtypes = [C.c_void_p] * 4
+
+    def __del__(self):
+        try:
+            self.L.orc_pnp_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_ransac(self, probability=0.99, min_inliers=8, max_iterations=300, min_set=4, epsilon=0.4, th2=5.991):
+        self.L.orc_pnp_set_ransac(self.h, probability, min_inliers, max_iterations, min_set, epsilon, th2)
+
+    def params(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self.L.orc_pnp_params(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(N=a.value, min_inliers=b.value, max_its=c.value)
+
+    def iterate(self, n_iterations, rand_stream=None):
+        T = np.zeros(16, np.float32)
+        inl = np.zeros(self.n, np.uint8)
+        nin, nomore, done = C.c_int(), C.c_int(), C.c_int()
+        rs = None if rand_stream is None else np.ascontiguousarray(rand_stream, np.int32)
+        ok = self.L.orc_pnp_iterate(self.h, n_iterations, _p(rs) if rs is not None else None, 0 if rs is None else len(rs),
+                                    _p(T), _p(inl), C.byref(nin), C.byref(nomore), C.byref(done))
+        return dict(ok=bool(ok), T=T.reshape(4, 4).copy(), inliers=inl.astype(bool), n_inliers=nin.value,
+                    no_more=bool(nomore.value), iterations=done.value)
+
+
+def epnp(Xw, uv, K):
+    Xw = np.ascontiguousarray(Xw, np.float64)
+    uv = np.ascontiguousarray(uv, np.float64)
+    R = np.zeros(9)
+    t = np.zeros(3)
+    L = lib()
+    L.orc_epnp.restype = C.c_double
+    L.orc_epnp.argtypes = [C.c_int, C.c_void_p, C.c_void_p] + [C.c_double] * 4 + [C.c_void_p, C.c_void_p]
+    e = L.orc_epnp(len(Xw), _p(Xw), _p(uv), float(K[0]), float(K[1]), float(K[2]), float(K[3]), _p(R), _p(t))
+    return R.reshape(3, 3), t, e
+
+
+def svd_square(A):
+    A = np.ascontiguousarray(A, np.float64)
+    n = A.shape[0]
+    W, Ut, Vt = np.zeros(n), np.zeros((n, n)), np.zeros((n, n))
+    lib().orc_svd_square(_p(A), n, _p(W), _p(Ut), _p(Vt))
+    return W, Ut, Vt
+
+
+def glibc_rand_stream(n, seed=1):
+    """n raw rand() values of glibc's TYPE_3 additive-feedback generator seeded with `seed`
+    (the reference never seeds: SD_SLAM::Random draws from the default seed-1 state,
+    reference src/extra/utils.cc:23-26).  Restated, so tests do not perturb the process RNG."""
+    r = [0] * 34
+    r[0] = seed
+    for i in range(1, 31):
+        hi, lo = divmod(r[i - 1], 127773)
+        w = 16807 * lo - 2836 * hi
+        if w < 0:
+            w += 2147483647
+        r[i] = w
+    for i in range(31, 34):
+        r[i] = r[i - 31]
+    out = []
+    state = r[:]
+    k = 34
+    buf = state
+    for i in range(34, 344 + n):
+        v = (buf[i - 31] + buf[i - 3]) & 0xFFFFFFFF
+        buf.append(v)
+        if i >= 344:
+            out.append(v >> 1)
+    return np.array(out, np.int32)

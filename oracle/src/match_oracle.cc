@@ -1,0 +1,231 @@
+// ORACLE (test infrastructure only -- never linked into the product path).
+//
+// CPU restatement of the tracking-side matcher and the Frame grid it queries:
+//   Frame::AssignFeaturesToGrid / PosInGrid   reference src/Frame.cc:179-192, 323-332
+//   Frame::GetFeaturesInArea                  src/Frame.cc:271-321
+//   ORBmatcher::DescriptorDistance            src/ORBmatcher.cc:1459-1473
+//   ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)   src/ORBmatcher.cc:946-1075
+//   ORBmatcher::ComputeThreeMaxima            src/ORBmatcher.cc:1423-1454
+// MapPoint pointers are flattened to indices into the last frame's arrays: cur_match[i2] = index
+// of the last-frame map point assigned to current keypoint i2, or -1 (NULL).
+// Quirks kept: histogram factor 1/30, PosInGrid rounds while
+// GetFeaturesInArea floors/ceils, first strict minimum wins, later points overwrite earlier
+// assignments when the earlier point has Observations() == 0.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace orc {
+
+struct KeyPoint { float x, y, size, angle, response; int32_t octave, class_id; };
+
+static const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;   // src/Frame.h:34-35
+static const int TH_HIGH = 100, HISTO_LENGTH = 30;             // src/ORBmatcher.cc:36-38
+
+static int DescriptorDistance(const uint8_t* a, const uint8_t* b) {
+  const int32_t* pa = (const int32_t*)a;
+  const int32_t* pb = (const int32_t*)b;
+  int dist = 0;
+  for (int i = 0; i < 8; i++, pa++, pb++) {
+    unsigned int v = *pa ^ *pb;
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+struct FrameGrid {
+  int N;
+  const KeyPoint* keysUn;
+  float mnMinX, mnMaxX, mnMinY, mnMaxY, invW, invH;
+  std::vector<size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+
+  void build() {
+    invW = static_cast<float>(FRAME_GRID_COLS) / static_cast<float>(mnMaxX - mnMinX);
+    invH = static_cast<float>(FRAME_GRID_ROWS) / static_cast<float>(mnMaxY - mnMinY);
+    for (int i = 0; i < N; i++) {
+      const KeyPoint& kp = keysUn[i];
+      int posX = round((kp.x - mnMinX) * invW);
+      int posY = round((kp.y - mnMinY) * invH);
+      if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) continue;
+      mGrid[posX][posY].push_back(i);
+    }
+  }
+
+  std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel, const int maxLevel) const {
+    std::vector<size_t> vIndices;
+    const int nMinCellX = std::max(0, static_cast<int>(floor((x - mnMinX - r) * invW)));
+    if (nMinCellX >= FRAME_GRID_COLS) return vIndices;
+    const int nMaxCellX = std::min(static_cast<int>(FRAME_GRID_COLS - 1), static_cast<int>(ceil((x - mnMinX + r) * invW)));
+    if (nMaxCellX < 0) return vIndices;
+    const int nMinCellY = std::max(0, static_cast<int>(floor((y - mnMinY - r) * invH)));
+    if (nMinCellY >= FRAME_GRID_ROWS) return vIndices;
+    const int nMaxCellY = std::min(static_cast<int>(FRAME_GRID_ROWS - 1), static_cast<int>(ceil((y - mnMinY + r) * invH)));
+    if (nMaxCellY < 0) return vIndices;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+        const std::vector<size_t>& vCell = mGrid[ix][iy];
+        for (size_t j = 0, jend = vCell.size(); j < jend; j++) {
+          const KeyPoint& kpUn = keysUn[vCell[j]];
+          if (bCheckLevels) {
+            if (kpUn.octave < minLevel) continue;
+            if (maxLevel >= 0)
+              if (kpUn.octave > maxLevel) continue;
+          }
+          const float distx = kpUn.x - x;
+          const float disty = kpUn.y - y;
+          if (fabs(distx) < r && fabs(disty) < r) vIndices.push_back(vCell[j]);
+        }
+      }
+    }
+    return vIndices;
+  }
+};
+
+static void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = histo[i].size();
+    if (s > max1) {
+      max3 = max2; max2 = max1; max1 = s;
+      ind3 = ind2; ind2 = ind1; ind1 = i;
+    } else if (s > max2) {
+      max3 = max2; max2 = s;
+      ind3 = ind2; ind2 = i;
+    } else if (s > max3) {
+      max3 = s;
+      ind3 = i;
+    }
+  }
+  if (max2 < 0.1f * (float)max1) {
+    ind2 = -1;
+    ind3 = -1;
+  } else if (max3 < 0.1f * (float)max1) {
+    ind3 = -1;
+  }
+}
+
+}  // namespace orc
+
+using namespace orc;
+
+extern "C" {
+
+// Poses: 16 doubles column-major.  valid[i] != 0 <=> LastFrame.mvpMapPoints[i] != NULL && !mvbOutlier[i].
+// cur_match (N, in/out): -1 = NULL.  Returns nmatches (may count a keypoint twice exactly like the
+// reference does when an assignment is overwritten).
+int orc_search_by_projection(int N, const void* keysUn_, const uint8_t* desc, const float* uRight, const float* scaleFactors,
+                             float minX, float maxX, float minY, float maxY, float fx, float fy, float cx, float cy, float mbf,
+                             float mb, const double* Tcw_cm, const double* Tlw_cm, int M, const uint8_t* valid, const double* Xw,
+                             const uint8_t* mp_desc, const int* last_octave, const float* last_angle, const int* mp_obs, float th,
+                             int bMono, int checkOri, int* cur_match) {
+  const KeyPoint* keysUn = (const KeyPoint*)keysUn_;
+  FrameGrid G;
+  G.N = N;
+  G.keysUn = keysUn;
+  G.mnMinX = minX; G.mnMaxX = maxX; G.mnMinY = minY; G.mnMaxY = maxY;
+  G.build();
+
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  auto at = [](const double* T, int r, int c) { return T[c * 4 + r]; };
+  double Rcw[3][3], tcw[3], Rlw[3][3], tlw[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) {
+      Rcw[i][j] = at(Tcw_cm, i, j);
+      Rlw[i][j] = at(Tlw_cm, i, j);
+    }
+    tcw[i] = at(Tcw_cm, i, 3);
+    tlw[i] = at(Tlw_cm, i, 3);
+  }
+  double twc[3], tlc[3];
+  for (int i = 0; i < 3; i++) twc[i] = (-Rcw[0][i]) * tcw[0] + (-Rcw[1][i]) * tcw[1] + (-Rcw[2][i]) * tcw[2];
+  for (int i = 0; i < 3; i++) tlc[i] = (Rlw[i][0] * twc[0] + Rlw[i][1] * twc[1] + Rlw[i][2] * twc[2]) + tlw[i];
+  const bool bForward = tlc[2] > mb && !bMono;
+  const bool bBackward = -tlc[2] > mb && !bMono;
+
+  for (int i = 0; i < M; i++) {
+    if (!valid[i]) continue;
+    const double* x3Dw = Xw + 3 * i;
+    double x3Dc[3];
+    for (int r = 0; r < 3; r++) x3Dc[r] = (Rcw[r][0] * x3Dw[0] + Rcw[r][1] * x3Dw[1] + Rcw[r][2] * x3Dw[2]) + tcw[r];
+    const float xc = x3Dc[0];
+    const float yc = x3Dc[1];
+    const float invzc = 1.0 / x3Dc[2];
+    if (invzc < 0) continue;
+    float u = fx * xc * invzc + cx;
+    float v = fy * yc * invzc + cy;
+    if (u < minX || u > maxX) continue;
+    if (v < minY || v > maxY) continue;
+    int nLastOctave = last_octave[i];
+    float radius = th * scaleFactors[nLastOctave];
+    std::vector<size_t> vIndices2;
+    if (bForward) vIndices2 = G.GetFeaturesInArea(u, v, radius, nLastOctave, -1);
+    else if (bBackward) vIndices2 = G.GetFeaturesInArea(u, v, radius, 0, nLastOctave);
+    else vIndices2 = G.GetFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = mp_desc + 32 * (size_t)i;
+    int bestDist = 256;
+    int bestIdx2 = -1;
+    for (size_t k = 0; k < vIndices2.size(); k++) {
+      const size_t i2 = vIndices2[k];
+      if (cur_match[i2] >= 0)
+        if (mp_obs[cur_match[i2]] > 0) continue;
+      if (uRight && uRight[i2] > 0) {
+        const float ur = u - mbf * invzc;
+        const float er = fabs(ur - uRight[i2]);
+        if (er > radius) continue;
+      }
+      const int dist = DescriptorDistance(dMP, desc + 32 * i2);
+      if (dist < bestDist) {
+        bestDist = dist;
+        bestIdx2 = i2;
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      cur_match[bestIdx2] = i;
+      nmatches++;
+      if (checkOri) {
+        float rot = last_angle[i] - keysUn[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+          cur_match[rotHist[i][j]] = -1;
+          nmatches--;
+        }
+      }
+    }
+  }
+  return nmatches;
+}
+
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
+
+// GetFeaturesInArea exposed for known-answer tests; returns count, indices in reference order
+int orc_features_in_area(int N, const void* keysUn, float minX, float maxX, float minY, float maxY, float x, float y, float r,
+                         int minLevel, int maxLevel, int* out, int cap) {
+  FrameGrid G;
+  G.N = N;
+  G.keysUn = (const KeyPoint*)keysUn;
+  G.mnMinX = minX; G.mnMaxX = maxX; G.mnMinY = minY; G.mnMaxY = maxY;
+  G.build();
+  std::vector<size_t> v = G.GetFeaturesInArea(x, y, r, minLevel, maxLevel);
+  for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int)v[i];
+  return (int)v.size();
+}
+
+}  // extern "C"

@@ -31,3 +31,96 @@ def make_image(seed: int, w: int = 640, h: int = 480) -> np.ndarray:
 
 def make_batch(seed0: int, n: int, w: int = 640, h: int = 480) -> np.ndarray:
     return np.stack([make_image(seed0 + i, w, h) for i in range(n)])
+
+
+# ----------------------------------------------------------------------------------------
+# C3/C4 scene: textured plane Z = 2 m seen from two nearby poses
+# ----------------------------------------------------------------------------------------
+FX, FY, CX, CY = 500.0, 500.0, 320.0, 240.0      # Examples/Example.yaml-style pinhole, no distortion
+
+
+def se3_exp(upsilon, omega_deg):
+    """Rigid transform from translation-first twist (metres, degrees); plain Rodrigues."""
+    w = np.deg2rad(np.asarray(omega_deg, np.float64))
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        R, V = np.eye(3) + K, np.eye(3)
+    else:
+        R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = V @ np.asarray(upsilon, np.float64)
+    return T
+
+
+def _bilinear(tex, x, y):
+    h, w = tex.shape
+    x = np.clip(x, 0, w - 1.001)
+    y = np.clip(y, 0, h - 1.001)
+    x0 = np.floor(x).astype(np.int64)
+    y0 = np.floor(y).astype(np.int64)
+    fx, fy = x - x0, y - y0
+    t = tex.astype(np.float64)
+    v = (t[y0, x0] * (1 - fx) * (1 - fy) + t[y0, x0 + 1] * fx * (1 - fy) + t[y0 + 1, x0] * (1 - fx) * fy +
+         t[y0 + 1, x0 + 1] * fx * fy)
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+def surface_z(X, Y, depth=2.0):
+    """Gently curved scene surface Z = f(X, Y) (non-planar on purpose: EPnP as restated in the
+    reference has no planar special case)."""
+    return depth + 0.3 * np.sin(1.3 * X + 0.4) * np.cos(1.1 * Y - 0.2) + 0.1 * X
+
+
+def intersect_surface(Ow, dw, depth=2.0, iters=24):
+    """Ray/surface intersection by fixed-point iteration on the ray parameter (|slope| < 1)."""
+    s = (depth - Ow[2]) / dw[..., 2]
+    for _ in range(iters):
+        X = Ow[0] + dw[..., 0] * s
+        Y = Ow[1] + dw[..., 1] * s
+        s = (surface_z(X, Y, depth) - Ow[2]) / dw[..., 2]
+    return Ow + dw * s[..., None]
+
+
+def render_plane_view(tex, Tcw, w=640, h=480, depth=2.0):
+    """Image of the textured scene surface; the texture (2x the image resolution) is painted on
+    the surface along Z, i.e. texel = 2 * projection of (X, Y) onto the canonical Z=depth view."""
+    R, t = Tcw[:3, :3], Tcw[:3, 3]
+    v, u = np.mgrid[0:h, 0:w].astype(np.float64)
+    rays = np.stack([(u - CX) / FX, (v - CY) / FY, np.ones_like(u)], -1)        # camera frame
+    Rwc = R.T
+    Ow = -Rwc @ t
+    dw = rays @ Rwc.T                                                          # world directions
+    Xw = intersect_surface(Ow, dw, depth)
+    ur = FX * Xw[..., 0] / depth + CX
+    vr = FY * Xw[..., 1] / depth + CY
+    return _bilinear(tex, 2.0 * ur + 0.5, 2.0 * vr + 0.5)
+
+
+def make_scene(seed: int, upsilon=(0.02, -0.01, 0.015), omega_deg=(0.4, -0.3, 0.5), w=640, h=480):
+    """Two views of the textured surface: ref pose = identity, cur pose = Exp(upsilon, omega)."""
+    tex = make_image(seed, 2 * w, 2 * h)
+    T_ref = np.eye(4)
+    T_cur = se3_exp(upsilon, omega_deg)
+    return dict(ref=render_plane_view(tex, T_ref, w, h), cur=render_plane_view(tex, T_cur, w, h),
+                T_ref=T_ref, T_cur=T_cur, K=(FX, FY, CX, CY), depth=2.0)
+
+
+def backproject_on_surface(xy, depth=2.0):
+    """World points (ref pose = identity) hit by the rays through ref-image pixels."""
+    xy = np.asarray(xy, np.float64)
+    rays = np.stack([(xy[:, 0] - CX) / FX, (xy[:, 1] - CY) / FY, np.ones(len(xy))], -1)
+    return intersect_surface(np.zeros(3), rays, depth)
+
+
+def tracking_case(seed: int, ref_kps, ref_desc, max_points=300, **kw):
+    """Last-frame data of a TrackWithMotionModel step: the first `max_points` ref keypoints carry
+    map points (the surface points they see), described by the ref descriptors."""
+    n = len(ref_kps)
+    valid = np.zeros(n, np.uint8)
+    valid[:min(n, max_points)] = 1
+    Xw = backproject_on_surface(np.stack([ref_kps["x"], ref_kps["y"]], 1))
+    return dict(valid=valid, Xw=Xw, desc=ref_desc.copy(), octave=ref_kps["octave"].astype(np.int32).copy(),
+                angle=ref_kps["angle"].astype(np.float32).copy(), obs=np.ones(n, np.int32))
