@@ -111,6 +111,62 @@ int sd_dev_upload(void* dst, const void* src, size_t bytes);
 int sd_dev_download(void* dst, const void* src, size_t bytes);
 
 /* ------------------------------------------------------------------------------------------
+ * Batched TrackWithMotionModel context -- the per-frame sequence of src/Tracking.cc:654-718
+ * over two resident extractor handles: `cur` holds the current frames of the batch, `ref` the
+ * last frames (same geometry, frame f of one pairs with frame f of the other).
+ *
+ *   sd_track_align   ImageAlign::ComputePose            src/ImageAlign.h:36-42, src/ImageAlign.cc:45-232
+ *                    mode 0 (Frame,Frame) / 1 (Frame,KeyFrame) / 2 (Frame,KeyFrame,fast) / 3 (KF,KF)
+ *   sd_track_match   ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)
+ *                                                       src/ORBmatcher.h:46, src/ORBmatcher.cc:946-1075
+ *                    (+ Frame::AssignFeaturesToGrid / GetFeaturesInArea, src/Frame.cc:179-192,271-332)
+ *   sd_track_pnp     PnPsolver ctor + SetRansacParameters + iterate
+ *                                                       src/PnPsolver.h:67-76, src/PnPsolver.cc:71-315
+ *
+ * Last-frame data (sd_track_set_last) flattens LastFrame.mvpMapPoints: for last-frame keypoint
+ * i, valid[i] = (pMP != NULL && !mvbOutlier[i]), Xw = pMP->GetWorldPos(), desc =
+ * pMP->GetDescriptor(), octave = mvKeys[i].octave, angle = mvKeysUn[i].angle, obs =
+ * pMP->Observations().  Arrays are [n_frames][max_points(...)] in host memory.  Poses are 16
+ * doubles column-major (Eigen::Matrix4d::data()).  All launches are asynchronous on the `cur`
+ * extractor's stream; the sd_track_get_* calls synchronise.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sd_track sd_track;
+
+int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int pnp_max_iterations,
+                    sd_track** out);
+void sd_track_destroy(sd_track* h);
+/* Frame statics: fx, fy, cx, cy, mbf, mnMinX, mnMaxX, mnMinY, mnMaxY (src/Frame.cc:158-174) */
+int sd_track_set_camera(sd_track* h, float fx, float fy, float cx, float cy, float bf,
+                        float min_x, float max_x, float min_y, float max_y);
+int sd_track_set_last(sd_track* h, int frame0, int n_frames, const int32_t* n_last,
+                      const uint8_t* valid, const double* Xw, const uint8_t* desc,
+                      const int32_t* octave, const float* angle, const int32_t* obs);
+int sd_track_set_poses(sd_track* h, int frame0, int n_frames, const double* Tref_cm,
+                       const double* Tcur_cm);
+/* raw rand() values consumed by SD_SLAM::Random, 4 per RANSAC iteration (src/extra/utils.cc:23-26,
+ * src/PnPsolver.cc:185-194); rand_values is [n_frames][per_frame] */
+int sd_track_set_rand(sd_track* h, int frame0, int n_frames, const int32_t* rand_values, int per_frame);
+
+int sd_track_align(sd_track* h, int n_frames, int mode);
+int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori);
+int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers, int max_iterations,
+                 int min_set, float epsilon, float th2, int n_iterations);
+
+/* ImageAlign results: pose written by CurrentFrame.SetPose (unchanged when ok == 0 or mode 3),
+ * GetError(), the bool return, iterations per pyramid level (n x 16) and chi2_ */
+int sd_track_get_align(sd_track* h, int frame0, int n_frames, double* Tcur_cm, double* error,
+                       int32_t* ok, int32_t* iters, double* chi2);
+/* CurrentFrame.mvpMapPoints as indices into the last-frame arrays (-1 = NULL), return value */
+int sd_track_get_matches(sd_track* h, int frame0, int n_frames, int32_t* cur_match, int cap,
+                         int32_t* n_matches);
+/* iterate(): Tcw (4x4 CV_32F row-major; all zeros = empty Mat), vbInliers, and per frame
+ * info8 = {returned(0/1), nInliers, bNoMore, iterations, N, minInliers, maxIts, refined} */
+int sd_track_get_pnp(sd_track* h, int frame0, int n_frames, float* Tcw_rowmajor, uint8_t* inliers,
+                     int cap, int32_t* info8);
+int sd_track_set_profiling(sd_track* h, int on);
+int sd_track_stage_ms(sd_track* h, float* ms_out /* [0]=align, [1]=match */, int cap);
+
+/* ------------------------------------------------------------------------------------------
  * ORBmatcher::DescriptorDistance -- src/ORBmatcher.h:44, src/ORBmatcher.cc:1459-1473
  * (pure host function; kept in the ABI so callers need no second library)
  * ------------------------------------------------------------------------------------------ */

@@ -6,7 +6,7 @@ reference's class surface, used by tests/ and bench.py.  There is NO CPU fallbac
 works anywhere (so the symbol table can be checked), but every compute entry point fails
 loudly when the library or a GPU is missing.
 """
-from .capi import (KP_DTYPE, SdError, lib, lib_path, ORBextractor, device_count, hamming,  # noqa: F401
-                   plan_info)
+from .capi import (KP_DTYPE, SdError, lib, lib_path, ORBextractor, Tracker, DeviceBuffer, device_count,  # noqa: F401
+                   hamming, plan_info)
 
-__all__ = ["KP_DTYPE", "SdError", "lib", "lib_path", "ORBextractor", "device_count", "hamming", "plan_info"]
+__all__ = ["KP_DTYPE", "SdError", "lib", "lib_path", "ORBextractor", "Tracker", "DeviceBuffer", "device_count", "hamming", "plan_info"]

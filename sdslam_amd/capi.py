@@ -272,3 +272,130 @@ class ORBextractor:
         b = np.zeros(n, np.float64)
         _check(self.L.sd_orb_stage_bytes(self.h, _p(b), n))
         return b
+
+
+def _cm(T):
+    """4x4 (row-major math) -> 16 doubles column-major (Eigen::Matrix4d::data())."""
+    return np.ascontiguousarray(np.asarray(T, np.float64).T).ravel()
+
+
+def _from_cm(v):
+    return np.asarray(v, np.float64).reshape(4, 4).T.copy()
+
+
+class Tracker:
+    """Batched TrackWithMotionModel context over two resident extractors (sd_track_*):
+    ImageAlign.ComputePose -> ORBmatcher.SearchByProjection -> PnPsolver.iterate
+    (reference src/Tracking.cc:654-718)."""
+
+    MODE_FRAME, MODE_KF, MODE_KF_FAST, MODE_KFKF = 0, 1, 2, 3
+
+    def __init__(self, cur: ORBextractor, ref: ORBextractor, max_points=1000, max_batch=1, pnp_max_iterations=300):
+        self.L = lib()
+        L = self.L
+        L.sd_track_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.sd_track_destroy.argtypes = [C.c_void_p]
+        L.sd_track_set_camera.argtypes = [C.c_void_p] + [C.c_float] * 9
+        L.sd_track_set_last.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
+        L.sd_track_set_poses.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.sd_track_set_rand.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.sd_track_align.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.sd_track_match.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int]
+        L.sd_track_pnp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
+        L.sd_track_get_align.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.sd_track_get_matches.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.sd_track_get_pnp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.sd_track_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.sd_track_stage_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.cur, self.ref = cur, ref
+        self.M, self.B, self.cap = max_points, max_batch, cur.cap
+        self.h = C.c_void_p()
+        _check(L.sd_track_create(cur.h, ref.h, max_points, max_batch, pnp_max_iterations, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.sd_track_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_camera(self, fx, fy, cx, cy, bf=0.0, bounds=(0.0, 640.0, 0.0, 480.0)):
+        _check(self.L.sd_track_set_camera(self.h, fx, fy, cx, cy, bf, *[float(b) for b in bounds]))
+
+    def set_last(self, frame0, cases):
+        """cases: list of dict(valid, Xw, desc, octave, angle, obs) (one per frame)."""
+        n, M = len(cases), self.M
+        n_last = np.zeros(n, np.int32)
+        valid = np.zeros((n, M), np.uint8)
+        Xw = np.zeros((n, M, 3), np.float64)
+        desc = np.zeros((n, M, 32), np.uint8)
+        octave = np.zeros((n, M), np.int32)
+        angle = np.zeros((n, M), np.float32)
+        obs = np.zeros((n, M), np.int32)
+        for i, c in enumerate(cases):
+            k = len(c["valid"])
+            assert k <= M
+            n_last[i] = k
+            valid[i, :k], Xw[i, :k], desc[i, :k] = c["valid"], c["Xw"], c["desc"]
+            octave[i, :k], angle[i, :k], obs[i, :k] = c["octave"], c["angle"], c["obs"]
+        _check(self.L.sd_track_set_last(self.h, frame0, n, _p(n_last), _p(valid), _p(Xw), _p(desc), _p(octave), _p(angle),
+                                        _p(obs)))
+
+    def set_poses(self, frame0, T_ref_list, T_cur_list):
+        n = len(T_ref_list)
+        a = np.stack([_cm(T) for T in T_ref_list])
+        b = np.stack([_cm(T) for T in T_cur_list])
+        _check(self.L.sd_track_set_poses(self.h, frame0, n, _p(a), _p(b)))
+
+    def set_rand(self, frame0, rand_values):
+        r = np.ascontiguousarray(rand_values, np.int32)
+        assert r.ndim == 2
+        _check(self.L.sd_track_set_rand(self.h, frame0, r.shape[0], _p(r), r.shape[1]))
+
+    def align(self, n_frames, mode=0):
+        _check(self.L.sd_track_align(self.h, n_frames, mode))
+
+    def match(self, n_frames, th=8.0, mono=True, check_ori=True):
+        _check(self.L.sd_track_match(self.h, n_frames, th, int(mono), int(check_ori)))
+
+    def pnp(self, n_frames, probability=0.99, min_inliers=8, max_iterations=300, min_set=4, epsilon=0.4, th2=5.991,
+            n_iterations=None):
+        n_iterations = max_iterations if n_iterations is None else n_iterations
+        _check(self.L.sd_track_pnp(self.h, n_frames, probability, min_inliers, max_iterations, min_set, epsilon, th2,
+                                   n_iterations))
+
+    def get_align(self, frame0, n):
+        T = np.zeros((n, 16))
+        err = np.zeros(n)
+        ok = np.zeros(n, np.int32)
+        iters = np.zeros((n, 16), np.int32)
+        chi2 = np.zeros(n)
+        _check(self.L.sd_track_get_align(self.h, frame0, n, _p(T), _p(err), _p(ok), _p(iters), _p(chi2)))
+        return dict(T=[_from_cm(t) for t in T], error=err, ok=ok.astype(bool), iters=iters, chi2=chi2)
+
+    def get_matches(self, frame0, n):
+        cm = np.zeros((n, self.cap), np.int32)
+        nm = np.zeros(n, np.int32)
+        _check(self.L.sd_track_get_matches(self.h, frame0, n, _p(cm), self.cap, _p(nm)))
+        return cm, nm
+
+    def get_pnp(self, frame0, n):
+        T = np.zeros((n, 16), np.float32)
+        inl = np.zeros((n, self.cap), np.uint8)
+        info = np.zeros((n, 8), np.int32)
+        _check(self.L.sd_track_get_pnp(self.h, frame0, n, _p(T), _p(inl), self.cap, _p(info)))
+        return dict(T=T.reshape(n, 4, 4), inliers=inl.astype(bool), ok=info[:, 0].astype(bool), n_inliers=info[:, 1],
+                    no_more=info[:, 2].astype(bool), iterations=info[:, 3], N=info[:, 4], min_inliers=info[:, 5],
+                    max_its=info[:, 6], refined=info[:, 7].astype(bool))
+
+    def set_profiling(self, on=True):
+        _check(self.L.sd_track_set_profiling(self.h, int(on)))
+
+    def stage_ms(self):
+        ms = np.zeros(2, np.float32)
+        _check(self.L.sd_track_stage_ms(self.h, _p(ms), 2))
+        return ms

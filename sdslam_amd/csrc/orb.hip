@@ -624,41 +624,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
 // ==========================================================================================
 using namespace sd;
 
-enum { ST_PYR = 0, ST_FAST, ST_SELECT, ST_BLUR, ST_DESC, ST_COUNT };
+#include "orb_internal.h"
 static const char* kStageNames[ST_COUNT] = {"pyramid", "fast_nms", "select", "blur", "orient_desc"};
-
-struct sd_orb {
-  int nfeatures, nlevels, thFAST;
-  float scaleFactor;
-  int max_w, max_h, max_batch, device;
-  HostPlan hp;
-  bool have_geom = false;
-  int cur_w = 0, cur_h = 0;
-  int last_frames = 0;
-  hipStream_t own_stream = nullptr, stream = nullptr;
-  // device buffers
-  OrbPlan* d_plan = nullptr;
-  CellGeom* d_cells = nullptr;
-  BlurTile* d_tiles = nullptr;
-  int32_t* d_coef = nullptr;
-  uint8_t* d_img = nullptr;     // staging for host-input calls
-  uint8_t* d_pyr = nullptr;
-  uint8_t* d_blur = nullptr;
-  uint32_t* d_cand = nullptr;
-  uint32_t* d_scratch = nullptr;
-  int32_t* d_cell_count = nullptr;
-  uint32_t* d_sel = nullptr;
-  int32_t* d_sel_count = nullptr;
-  sd_keypoint* d_kps = nullptr;
-  uint8_t* d_desc = nullptr;
-  int32_t* d_nout = nullptr;
-  size_t cap_pyr = 0, cap_cand = 0, cap_cells = 0, cap_tiles = 0, cap_coef = 0;
-  bool profiling = false;
-  // ring of per-call stage events: the bench reads mean stage times over its whole timed region
-  static const int kRing = 128;
-  hipEvent_t ev[kRing][ST_COUNT + 1] = {};
-  int ev_calls = 0;   // calls recorded since profiling was (re-)enabled
-};
 
 static int free_geom(sd_orb* h) {
   void* ptrs[] = {h->d_cells, h->d_tiles, h->d_coef, h->d_pyr, h->d_blur, h->d_cand, h->d_scratch,

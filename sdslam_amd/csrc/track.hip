@@ -1,0 +1,313 @@
+// sd_track_*: batched TrackWithMotionModel context (ImageAlign -> SearchByProjection -> PnP)
+// over two resident extractor handles (current frames, last frames).  Host side only; the
+// kernels live in track_align.hip / track_match.hip / track_pnp.hip.
+//
+// Call sequence of the reference this mirrors (src/Tracking.cc:654-718):
+//   ImageAlign::ComputePose(cur, last)            -> sd_track_align
+//   ORBmatcher(0.9,true).SearchByProjection(...)  -> sd_track_match
+//   pose solve (PnPsolver per BASELINE; the reference calls Optimizer::PoseOptimization, D1)
+//                                                 -> sd_track_pnp
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "orb_internal.h"
+#include "track_internal.h"
+
+using namespace sd;
+
+struct sd_track {
+  sd_orb* cur = nullptr;
+  sd_orb* ref = nullptr;
+  int max_points = 0, max_batch = 0, kp_cap = 0, device = 0;
+  int rand_per_frame = 0;
+  TrackBuffers tb{};
+  TrackCam cam{};
+  bool have_cam = false;
+  float* d_sf = nullptr;
+  float* d_inv_sf = nullptr;
+  float* d_sigma2 = nullptr;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  bool profiling = false;
+  static const int kRing = 128;
+  hipEvent_t ev[kRing][4] = {};
+  int ev_calls[3] = {0, 0, 0};
+};
+
+template <typename T>
+static int dalloc(sd_track* h, T** p, size_t count) {
+  void* q = nullptr;
+  SD_HIP_CHECK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  SD_HIP_CHECK(hipMemset(q, 0, std::max<size_t>(count, 1) * sizeof(T)));
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return SD_OK;
+}
+
+extern "C" {
+
+int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int pnp_max_iterations, sd_track** out) {
+  SD_REQUIRE(out, SD_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  SD_REQUIRE(cur && ref, SD_ERR_INVALID_ARG, "extractor handle is NULL");
+  SD_REQUIRE(cur->device == ref->device && cur->nlevels == ref->nlevels && cur->scaleFactor == ref->scaleFactor,
+             SD_ERR_INVALID_ARG, "cur/ref extractors must share device and pyramid parameters");
+  SD_REQUIRE(max_points >= 1 && max_points <= 2048 && max_batch >= 1 && max_batch <= cur->max_batch && max_batch <= ref->max_batch,
+             SD_ERR_INVALID_ARG, "bad capacities (max_points <= 2048, max_batch <= extractor max_batch)");
+  SD_REQUIRE(pnp_max_iterations >= 1 && pnp_max_iterations <= 4096, SD_ERR_INVALID_ARG, "bad pnp_max_iterations");
+  int nsel = 0;
+  for (int q : cur->hp.quota) nsel += q;
+  SD_REQUIRE(nsel >= 1 && nsel <= 2048, SD_ERR_INVALID_ARG, "tracking supports at most 2048 keypoints per frame");
+  SD_HIP_CHECK(hipSetDevice(cur->device));
+  sd_track* h = new sd_track();
+  h->cur = cur;
+  h->ref = ref;
+  h->max_points = max_points;
+  h->max_batch = max_batch;
+  h->kp_cap = nsel;
+  h->device = cur->device;
+  h->stream = cur->stream;
+  h->rand_per_frame = 4 * pnp_max_iterations;
+  const size_t B = max_batch, M = max_points, K = nsel;
+  TrackBuffers& tb = h->tb;
+  tb.max_points = max_points;
+  tb.kp_cap = nsel;
+  int rc = SD_OK;
+  auto A = [&](int r) { if (rc == SD_OK) rc = r; };
+  A(dalloc(h, &tb.valid, B * M));
+  A(dalloc(h, &tb.Xw, B * M * 3));
+  A(dalloc(h, &tb.mp_desc, B * M * 32));
+  A(dalloc(h, &tb.octave, B * M));
+  A(dalloc(h, &tb.angle, B * M));
+  A(dalloc(h, &tb.obs, B * M));
+  A(dalloc(h, &tb.n_last, B));
+  A(dalloc(h, &tb.Tref, B * 16));
+  A(dalloc(h, &tb.Tcur, B * 16));
+  A(dalloc(h, &tb.al_ok, B));
+  A(dalloc(h, &tb.al_err, B));
+  A(dalloc(h, &tb.al_chi2, B));
+  A(dalloc(h, &tb.al_iters, B * 16));
+  A(dalloc(h, &tb.cur_match, B * K));
+  A(dalloc(h, &tb.n_matches, B));
+  A(dalloc(h, &tb.rand_stream, B * (size_t)h->rand_per_frame));
+  A(dalloc(h, &tb.pnp_T, B * 16));
+  A(dalloc(h, &tb.pnp_inliers, B * K));
+  A(dalloc(h, &tb.pnp_info, B * 8));
+  A(dalloc(h, &tb.pnp_scratch, B * K * 12));
+  A(dalloc(h, &h->d_sf, (size_t)cur->nlevels));
+  A(dalloc(h, &h->d_inv_sf, (size_t)cur->nlevels));
+  A(dalloc(h, &h->d_sigma2, (size_t)cur->nlevels));
+  if (rc == SD_OK) {
+    hipError_t e = hipMemcpy(h->d_sf, cur->hp.sf.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_inv_sf, cur->hp.inv_sf.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_sigma2, cur->hp.sigma2.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
+    for (int r = 0; r < sd_track::kRing && e == hipSuccess; r++)
+      for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
+    if (e != hipSuccess) {
+      set_error(std::string("sd_track_create: ") + hipGetErrorString(e));
+      rc = SD_ERR_HIP;
+    }
+  }
+  if (rc != SD_OK) {
+    sd_track_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return SD_OK;
+}
+
+void sd_track_destroy(sd_track* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (int r = 0; r < sd_track::kRing; r++)
+    for (int i = 0; i < 4; i++)
+      if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
+  delete h;
+}
+
+int sd_track_set_camera(sd_track* h, float fx, float fy, float cx, float cy, float bf, float min_x, float max_x, float min_y,
+                        float max_y) {
+  SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  SD_REQUIRE(fx > 0 && fy > 0 && max_x > min_x && max_y > min_y, SD_ERR_INVALID_ARG, "bad camera parameters");
+  TrackCam& c = h->cam;
+  c.ffx = fx; c.ffy = fy; c.fcx = cx; c.fcy = cy;
+  c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy;
+  c.min_x = min_x; c.max_x = max_x; c.min_y = min_y; c.max_y = max_y;
+  c.bf = bf;
+  c.mb = bf / fx;
+  h->have_cam = true;
+  return SD_OK;
+}
+
+#define TRACK_RANGE(h, frame0, n)                                                                        \
+  SD_REQUIRE((h), SD_ERR_INVALID_ARG, "handle is NULL");                                                 \
+  SD_REQUIRE((frame0) >= 0 && (n) >= 1 && (frame0) + (n) <= (h)->max_batch, SD_ERR_CAPACITY, "frame range exceeds max_batch"); \
+  SD_HIP_CHECK(hipSetDevice((h)->device))
+
+int sd_track_set_last(sd_track* h, int frame0, int n_frames, const int32_t* n_last, const uint8_t* valid, const double* Xw,
+                      const uint8_t* desc, const int32_t* octave, const float* angle, const int32_t* obs) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(n_last && valid && Xw && desc && octave && angle && obs, SD_ERR_INVALID_ARG, "NULL argument");
+  const size_t M = h->max_points, o = (size_t)frame0;
+  for (int f = 0; f < n_frames; f++) SD_REQUIRE(n_last[f] >= 0 && n_last[f] <= h->max_points, SD_ERR_CAPACITY, "n_last exceeds max_points");
+  hipStream_t s = h->stream;
+  const TrackBuffers& tb = h->tb;
+  SD_HIP_CHECK(hipMemcpyAsync(tb.n_last + o, n_last, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.valid + o * M, valid, n_frames * M, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.Xw + o * M * 3, Xw, n_frames * M * 3 * 8, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.mp_desc + o * M * 32, desc, n_frames * M * 32, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.octave + o * M, octave, n_frames * M * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.angle + o * M, angle, n_frames * M * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.obs + o * M, obs, n_frames * M * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
+}
+
+int sd_track_set_poses(sd_track* h, int frame0, int n_frames, const double* Tref_cm, const double* Tcur_cm) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(Tref_cm && Tcur_cm, SD_ERR_INVALID_ARG, "NULL argument");
+  SD_HIP_CHECK(hipMemcpyAsync(h->tb.Tref + (size_t)frame0 * 16, Tref_cm, (size_t)n_frames * 128, hipMemcpyHostToDevice, h->stream));
+  SD_HIP_CHECK(hipMemcpyAsync(h->tb.Tcur + (size_t)frame0 * 16, Tcur_cm, (size_t)n_frames * 128, hipMemcpyHostToDevice, h->stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SD_OK;
+}
+
+int sd_track_set_rand(sd_track* h, int frame0, int n_frames, const int32_t* rand_values, int per_frame) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(rand_values && per_frame >= 1 && per_frame <= h->rand_per_frame, SD_ERR_INVALID_ARG, "bad rand stream");
+  SD_HIP_CHECK(hipMemcpy2DAsync(h->tb.rand_stream + (size_t)frame0 * h->rand_per_frame, (size_t)h->rand_per_frame * 4, rand_values,
+                                (size_t)per_frame * 4, (size_t)per_frame * 4, n_frames, hipMemcpyHostToDevice, h->stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SD_OK;
+}
+
+static int check_ready(sd_track* h, int n_frames) {
+  SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  SD_REQUIRE(h->have_cam, SD_ERR_INVALID_ARG, "sd_track_set_camera has not been called");
+  SD_REQUIRE(n_frames >= 1 && n_frames <= h->max_batch, SD_ERR_CAPACITY, "n_frames exceeds max_batch");
+  SD_REQUIRE(h->cur->have_geom && h->cur->last_frames >= n_frames, SD_ERR_INVALID_ARG, "current frames have not been extracted");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  return SD_OK;
+}
+
+static int prof_begin(sd_track* h, int which) {
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(h->ev[h->ev_calls[which] % sd_track::kRing][which == 0 ? 0 : which], h->cur->stream));
+  return SD_OK;
+}
+
+int sd_track_align(sd_track* h, int n_frames, int mode) {
+  int rc = check_ready(h, n_frames);
+  if (rc != SD_OK) return rc;
+  SD_REQUIRE(mode >= 0 && mode <= 3, SD_ERR_INVALID_ARG, "bad mode");
+  SD_REQUIRE(h->ref->have_geom && h->ref->last_frames >= n_frames && h->ref->cur_w == h->cur->cur_w && h->ref->cur_h == h->cur->cur_h,
+             SD_ERR_INVALID_ARG, "reference frames not extracted or of different size");
+  hipStream_t s = h->cur->stream;
+  hipEvent_t* ev = h->ev[h->ev_calls[0] % sd_track::kRing];
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[0], s));
+  rc = launch_align(h->cur, h->ref, h->tb, h->cam, h->d_inv_sf, h->d_sf, n_frames, mode, s);
+  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[1], s)); h->ev_calls[0]++; }
+  return rc;
+}
+
+int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori) {
+  int rc = check_ready(h, n_frames);
+  if (rc != SD_OK) return rc;
+  SD_REQUIRE(mono != 0, SD_ERR_INVALID_ARG, "only monocular frames are supported in this round (mvuRight == -1)");
+  hipStream_t s = h->cur->stream;
+  hipEvent_t* ev = h->ev[h->ev_calls[1] % sd_track::kRing];
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[2], s));
+  rc = launch_match(h->cur, h->tb, h->cam, h->d_sf, n_frames, th, mono, check_ori, s);
+  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[3], s)); h->ev_calls[1]++; }
+  return rc;
+}
+
+int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers, int max_iterations, int min_set, float epsilon,
+                 float th2, int n_iterations) {
+  int rc = check_ready(h, n_frames);
+  if (rc != SD_OK) return rc;
+  SD_REQUIRE(min_set == 4, SD_ERR_INVALID_ARG, "minSet must be 4 (EPnP minimal set)");
+  SD_REQUIRE(max_iterations >= 1 && 4 * std::max(max_iterations, n_iterations) <= h->rand_per_frame, SD_ERR_CAPACITY,
+             "iterations exceed the handle's pnp_max_iterations");
+  PnpParams pp;
+  pp.probability = probability;
+  pp.min_inliers = min_inliers;
+  pp.max_iterations = max_iterations;
+  pp.min_set = min_set;
+  pp.epsilon = epsilon;
+  pp.th2 = th2;
+  pp.n_iterations = n_iterations;
+  pp.rand_per_frame = h->rand_per_frame;
+  return launch_pnp(h->cur, h->tb, h->cam, h->d_sigma2, pp, n_frames, h->cur->stream);
+}
+
+int sd_track_get_align(sd_track* h, int frame0, int n_frames, double* Tcur_cm, double* error, int32_t* ok, int32_t* iters,
+                       double* chi2) {
+  TRACK_RANGE(h, frame0, n_frames);
+  hipStream_t s = h->cur->stream;
+  const size_t o = frame0, n = n_frames;
+  if (Tcur_cm) SD_HIP_CHECK(hipMemcpyAsync(Tcur_cm, h->tb.Tcur + o * 16, n * 128, hipMemcpyDeviceToHost, s));
+  if (error) SD_HIP_CHECK(hipMemcpyAsync(error, h->tb.al_err + o, n * 8, hipMemcpyDeviceToHost, s));
+  if (ok) SD_HIP_CHECK(hipMemcpyAsync(ok, h->tb.al_ok + o, n * 4, hipMemcpyDeviceToHost, s));
+  if (iters) SD_HIP_CHECK(hipMemcpyAsync(iters, h->tb.al_iters + o * 16, n * 64, hipMemcpyDeviceToHost, s));
+  if (chi2) SD_HIP_CHECK(hipMemcpyAsync(chi2, h->tb.al_chi2 + o, n * 8, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
+}
+
+int sd_track_get_matches(sd_track* h, int frame0, int n_frames, int32_t* cur_match, int cap, int32_t* n_matches) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(!cur_match || cap >= h->kp_cap, SD_ERR_CAPACITY, "cap smaller than the keypoint capacity");
+  hipStream_t s = h->cur->stream;
+  if (cur_match)
+    SD_HIP_CHECK(hipMemcpy2DAsync(cur_match, (size_t)cap * 4, h->tb.cur_match + (size_t)frame0 * h->kp_cap, (size_t)h->kp_cap * 4,
+                                  (size_t)h->kp_cap * 4, n_frames, hipMemcpyDeviceToHost, s));
+  if (n_matches) SD_HIP_CHECK(hipMemcpyAsync(n_matches, h->tb.n_matches + frame0, (size_t)n_frames * 4, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
+}
+
+int sd_track_get_pnp(sd_track* h, int frame0, int n_frames, float* Tcw_rowmajor, uint8_t* inliers, int cap, int32_t* info8) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(!inliers || cap >= h->kp_cap, SD_ERR_CAPACITY, "cap smaller than the keypoint capacity");
+  hipStream_t s = h->cur->stream;
+  if (Tcw_rowmajor) SD_HIP_CHECK(hipMemcpyAsync(Tcw_rowmajor, h->tb.pnp_T + (size_t)frame0 * 16, (size_t)n_frames * 64, hipMemcpyDeviceToHost, s));
+  if (inliers)
+    SD_HIP_CHECK(hipMemcpy2DAsync(inliers, cap, h->tb.pnp_inliers + (size_t)frame0 * h->kp_cap, h->kp_cap, h->kp_cap, n_frames,
+                                  hipMemcpyDeviceToHost, s));
+  if (info8) SD_HIP_CHECK(hipMemcpyAsync(info8, h->tb.pnp_info + (size_t)frame0 * 8, (size_t)n_frames * 32, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
+}
+
+int sd_track_set_profiling(sd_track* h, int on) {
+  SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  h->profiling = on != 0;
+  h->ev_calls[0] = h->ev_calls[1] = h->ev_calls[2] = 0;
+  return SD_OK;
+}
+
+// mean ms of the align and match launches since profiling was switched on: ms_out[0] = align, [1] = match
+int sd_track_stage_ms(sd_track* h, float* ms_out, int cap) {
+  SD_REQUIRE(h && ms_out && cap >= 2, SD_ERR_INVALID_ARG, "bad arguments");
+  SD_REQUIRE(h->profiling, SD_ERR_INVALID_ARG, "profiling is off");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipStreamSynchronize(h->cur->stream));
+  for (int k = 0; k < 2; k++) {
+    ms_out[k] = 0;
+    const int n = std::min(h->ev_calls[k], (int)sd_track::kRing);
+    for (int r = 0; r < n; r++) {
+      float ms = 0;
+      const int slot = (h->ev_calls[k] - 1 - r) % sd_track::kRing;
+      SD_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[slot][2 * k], h->ev[slot][2 * k + 1]));
+      ms_out[k] += ms / n;
+    }
+  }
+  return SD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,458 @@
+// ImageAlign on MI355X: sparse direct (inverse-compositional) photometric alignment, one
+// workgroup per frame pair, persistent over pyramid levels and Gauss-Newton iterations.
+//
+// Replaces SD_SLAM::ImageAlign::ComputePose / Optimize / ComputeResiduals / PrecomputePatches
+// (reference src/ImageAlign.cc:45-421) and Exp/RotationExp (:473-517).
+//
+// Work split (256 threads, <= 300 points x 16 patch pixels = 4800 pixel slots, 19 per thread):
+//   * each thread keeps its pixels' reference patch value and image gradient (dx, dy) in
+//     registers for the whole level -- the reference's 230 KB fp64 jacobian_cache_ is never
+//     materialised: J = (dx*Jrow0 + dy*Jrow1)*(fx*scale) is recomputed from the point's
+//     reference-frame coordinates (LDS) with the same operations, hence the same values;
+//   * H (21 upper entries) and Jres (6) are accumulated per thread in fp64 and combined with a
+//     fixed-shape wave-shuffle + LDS tree (deterministic run to run);
+//   * chi2 is accumulated in FLOAT in point/pixel order by one lane from per-pixel squares in LDS,
+//     i.e. bit-identical to the reference's sequential `chi2 += res*res` (src/ImageAlign.cc:298,341),
+//     so the accept / stop decisions (`new_chi2 > chi2_`, `> 0.99*chi2_`) do not flip;
+//   * lane 0 solves the 6x6 system (pivoted LDLT, Eigen 3.3 semantics) and updates se3.
+// Reproduced quirks: sticky visibility flags, sticky stop_/chi2_, fx on both
+// Jacobian rows, float chi2, double-then-float bilinear weights.  Images are read from the
+// padded pyramids the extractor left resident in HBM (levels 4,3,2 only).
+#include <hip/hip_runtime.h>
+
+#include "orb_internal.h"
+#include "track_internal.h"
+
+namespace sd {
+
+#define AL_MAXP 300
+#define AL_SLOTS 19   // ceil(300*16 / 256)
+
+struct Mat4 { double m[4][4]; };
+
+__device__ __forceinline__ void m4_mul(const double* a, const double* b, double* r) {   // row-major 4x4
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double s = 0;
+      for (int k = 0; k < 4; k++) s += a[i * 4 + k] * b[k * 4 + j];
+      r[i * 4 + j] = s;
+    }
+}
+
+// Eigen 3.3 LDLT<Matrix6d>::solve (pivoting on the largest |diagonal|, pseudo-inverse of D)
+__device__ void ldlt_solve6(double A[6][6], const double* b, double* x) {
+  const int n = 6;
+  int tr[6];
+  double temp[6];
+  for (int k = 0; k < n; ++k) {
+    int big = k;
+    double best = fabs(A[k][k]);
+    for (int i = k + 1; i < n; i++)
+      if (fabs(A[i][i]) > best) { best = fabs(A[i][i]); big = i; }
+    tr[k] = big;
+    if (k != big) {
+      int s = n - big - 1;
+      for (int j = 0; j < k; j++) { double t = A[k][j]; A[k][j] = A[big][j]; A[big][j] = t; }
+      for (int i = 0; i < s; i++) { double t = A[big + 1 + i][k]; A[big + 1 + i][k] = A[big + 1 + i][big]; A[big + 1 + i][big] = t; }
+      { double t = A[k][k]; A[k][k] = A[big][big]; A[big][big] = t; }
+      for (int i = k + 1; i < big; ++i) { double t = A[i][k]; A[i][k] = A[big][i]; A[big][i] = t; }
+    }
+    int rs = n - k - 1;
+    if (k > 0) {
+      for (int j = 0; j < k; j++) temp[j] = A[j][j] * A[k][j];
+      double s = 0;
+      for (int j = 0; j < k; j++) s += A[k][j] * temp[j];
+      A[k][k] -= s;
+      for (int i = 0; i < rs; i++) {
+        double t = 0;
+        for (int j = 0; j < k; j++) t += A[k + 1 + i][j] * temp[j];
+        A[k + 1 + i][k] -= t;
+      }
+    }
+    double akk = A[k][k];
+    bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) {
+      for (int j = 0; j < n; j++) tr[j] = j;
+      break;
+    }
+    if (rs > 0 && valid)
+      for (int i = 0; i < rs; i++) A[k + 1 + i][k] /= akk;
+  }
+  double d[6];
+  for (int i = 0; i < n; i++) d[i] = b[i];
+  for (int k = 0; k < n; k++)
+    if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++) d[i] -= A[i][j] * d[j];
+  const double tol = 2.2250738585072014e-308;
+  for (int i = 0; i < n; i++) {
+    if (fabs(A[i][i]) > tol) d[i] /= A[i][i];
+    else d[i] = 0;
+  }
+  for (int i = n - 1; i >= 0; i--)
+    for (int j = i + 1; j < n; j++) d[i] -= A[j][i] * d[j];
+  for (int k = n - 1; k >= 0; k--)
+    if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int i = 0; i < n; i++) x[i] = d[i];
+}
+
+// ImageAlign::Exp (translation-first twist) -> row-major 4x4
+__device__ void se3_exp(const double* update, double* res) {
+  const double* upsilon = update;
+  const double* omega = update + 3;
+  double theta = sqrt(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]);
+  double half_theta = 0.5 * theta;
+  double imag_factor;
+  double real_factor = cos(half_theta);
+  if (theta < 1e-10) {
+    double theta_sq = theta * theta;
+    double theta_po4 = theta_sq * theta_sq;
+    imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
+  } else {
+    imag_factor = sin(half_theta) / theta;
+  }
+  const double qw = real_factor, qx = imag_factor * omega[0], qy = imag_factor * omega[1], qz = imag_factor * omega[2];
+  double rot[3][3];
+  {
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw;
+    const double txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    rot[0][0] = 1 - (tyy + tzz); rot[0][1] = txy - twz; rot[0][2] = txz + twy;
+    rot[1][0] = txy + twz; rot[1][1] = 1 - (txx + tzz); rot[1][2] = tyz - twx;
+    rot[2][0] = txz - twy; rot[2][1] = tyz + twx; rot[2][2] = 1 - (txx + tyy);
+  }
+  double Om[3][3] = {{0, -omega[2], omega[1]}, {omega[2], 0, -omega[0]}, {-omega[1], omega[0], 0}};
+  double V[3][3];
+  if (theta < 1e-10) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) V[i][j] = rot[i][j];
+  } else {
+    double Om2[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += Om[i][k] * Om[k][j];
+        Om2[i][j] = s;
+      }
+    double theta_sq = theta * theta;
+    double c1 = (1 - cos(theta)) / (theta_sq);
+    double c2 = (theta - sin(theta)) / (theta_sq * theta);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) V[i][j] = ((i == j ? 1.0 : 0.0) + c1 * Om[i][j]) + c2 * Om2[i][j];
+  }
+  for (int i = 0; i < 16; i++) res[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) res[i * 4 + j] = rot[i][j];
+    res[i * 4 + 3] = V[i][0] * upsilon[0] + V[i][1] * upsilon[1] + V[i][2] * upsilon[2];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr_cur,
+                                               const uint8_t* __restrict__ pyr_ref, TrackBuffers tb, TrackCam cam,
+                                               const float* __restrict__ inv_sf, const float* __restrict__ sf, int mode) {
+  __shared__ double s_pts[AL_MAXP * 3];
+  __shared__ double s_xyz[AL_MAXP * 3];
+  __shared__ uint8_t s_vis[AL_MAXP + 4];
+  __shared__ float s_chi[AL_MAXP * 16];
+  __shared__ double s_red[4][28];
+  __shared__ double s_last[16], s_se3[16], s_pose[16], s_bk[16];
+  __shared__ int s_cnt[4];
+  __shared__ int s_ctrl[4];   // [0] break flag, [1] npts
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = tb.max_points;
+  const uint8_t* valid = tb.valid + (size_t)f * M;
+  const double* Xw = tb.Xw + (size_t)f * M * 3;
+  const int n_last = min(tb.n_last[f], M);
+  const int max_pts = (mode == 2 || mode == 3) ? 100 : 300;
+
+  // ---- gather the first max_pts valid world points, in index order (src/ImageAlign.cc:62-72)
+  int running = 0;
+  for (int base = 0; base < n_last && running < max_pts; base += 256) {
+    int i = base + tid;
+    bool fl = i < n_last && valid[i] != 0;
+    unsigned long long m = __ballot(fl);
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = running;
+    for (int w = 0; w < wave; w++) off += s_cnt[w];
+    int pos = off + __popcll(m & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+    if (fl && pos < max_pts) {
+      s_pts[pos * 3 + 0] = Xw[(size_t)i * 3 + 0];
+      s_pts[pos * 3 + 1] = Xw[(size_t)i * 3 + 1];
+      s_pts[pos * 3 + 2] = Xw[(size_t)i * 3 + 2];
+    }
+    running += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+  }
+  const int npts = min(running, max_pts);
+  for (int i = tid; i < AL_MAXP; i += 256) s_vis[i] = 0;
+
+  double* out_T = tb.Tcur + (size_t)f * 16;
+  if (P->nlevels <= 4 || npts == 0) {   // "Not enough pyramid levels" / "No points to track!"
+    if (tid == 0) {
+      tb.al_ok[f] = 0;
+      tb.al_err[f] = 1e10;
+      tb.al_chi2[f] = 1e10;
+      for (int l = 0; l < 16; l++) tb.al_iters[(size_t)f * 16 + l] = 0;
+    }
+    return;
+  }
+  if (tid == 0) {
+    // column-major in HBM (Eigen::Matrix4d::data()) -> row-major working copies
+    double last[16], cur[16], inv[16];
+    for (int c = 0; c < 4; c++)
+      for (int r = 0; r < 4; r++) {
+        last[r * 4 + c] = tb.Tref[(size_t)f * 16 + c * 4 + r];
+        cur[r * 4 + c] = out_T[c * 4 + r];
+      }
+    for (int i = 0; i < 16; i++) s_last[i] = last[i];
+    if (mode == 3) {
+      for (int i = 0; i < 16; i++) s_se3[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    } else {
+      // Frame::GetPoseInverse: [R^T | -R^T t]
+      for (int i = 0; i < 16; i++) inv[i] = (i % 5 == 0) ? 1.0 : 0.0;
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) inv[i * 4 + j] = last[j * 4 + i];
+      for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (-inv[i * 4 + k]) * last[k * 4 + 3];
+        inv[i * 4 + 3] = s;
+      }
+      double se3[16];
+      m4_mul(cur, inv, se3);
+      for (int i = 0; i < 16; i++) s_se3[i] = se3[i];
+    }
+  }
+  __syncthreads();
+
+  // persistent optimisation state (meaningful on thread 0 only)
+  double chi2_ = 1e10, error_ = 1e10;
+  bool stop_ = false;
+  int ok = 1;
+  int iters[16];
+  for (int l = 0; l < 16; l++) iters[l] = 0;
+
+  float r_patch[AL_SLOTS], r_dx[AL_SLOTS], r_dy[AL_SLOTS];
+#pragma unroll
+  for (int k = 0; k < AL_SLOTS; k++) r_patch[k] = r_dx[k] = r_dy[k] = 0.f;
+  unsigned jvalid = 0;
+
+  const int lvl_hi = 4, lvl_lo = (mode == 3) ? 4 : 2;
+  for (int level = lvl_hi; level >= lvl_lo; level--) {
+    const LevelGeom L = P->lv[level];
+    const float scale = (mode == 3) ? (float)(1.0 / sf[level]) : inv_sf[level];
+    const uint8_t* img_cur = pyr_cur + (size_t)f * P->pyr_frame_bytes + L.off + (size_t)SD_EDGE * L.pstride + SD_EDGE;
+    const uint8_t* img_ref = pyr_ref + (size_t)f * P->pyr_frame_bytes + L.off + (size_t)SD_EDGE * L.pstride + SD_EDGE;
+    const int cols = L.w, rows = L.h, step = L.pstride;
+    const double fscale = cam.fx * scale;   // cam_fx_*scale
+    jvalid = 0;                              // jacobian_cache_.setZero()
+    if (tid == 0)
+      for (int i = 0; i < 16; i++) s_bk[i] = s_se3[i];
+    bool small = false;
+
+    for (int it = 0; it < 30; it++) {
+      // ------------------------------------------------ PrecomputePatches (first iteration of a level)
+      if (it == 0) {
+#pragma unroll
+        for (int k = 0; k < AL_SLOTS; k++) {
+          const int p = tid + 256 * k;
+          const int pt = p >> 4, pix = p & 15;
+          if (pt < npts) {
+            const double p0 = s_pts[pt * 3], p1 = s_pts[pt * 3 + 1], p2 = s_pts[pt * 3 + 2];
+            double xc[3];
+            for (int i = 0; i < 3; i++) xc[i] = (s_last[i * 4] * p0 + s_last[i * 4 + 1] * p1 + s_last[i * 4 + 2] * p2) + s_last[i * 4 + 3];
+            const double invzc = 1.0 / xc[2];
+            if (!(invzc < 0)) {
+              const double u2 = cam.fx * xc[0] * invzc + cam.cx;
+              const double v2 = cam.fy * xc[1] * invzc + cam.cy;
+              const float u_ref = (float)(u2 * scale);
+              const float v_ref = (float)(v2 * scale);
+              const int ui = (int)floorf(u_ref), vi = (int)floorf(v_ref);
+              if (!(ui - 3 < 0 || vi - 3 < 0 || ui + 3 >= cols || vi + 3 >= rows)) {
+                if (pix == 0) {
+                  s_vis[pt] = 1;
+                  s_xyz[pt * 3] = xc[0];
+                  s_xyz[pt * 3 + 1] = xc[1];
+                  s_xyz[pt * 3 + 2] = xc[2];
+                }
+                const float su = u_ref - ui, sv = v_ref - vi;
+                const float w_tl = (float)((1.0 - su) * (1.0 - sv));
+                const float w_tr = (float)(su * (1.0 - sv));
+                const float w_bl = (float)((1.0 - su) * sv);
+                const float w_br = (float)(su * sv);
+                const int y = vi - 2 + (pix >> 2), x = ui - 2 + (pix & 3);
+                const uint8_t* rp = img_ref + (size_t)y * step + x;
+                const uint8_t* rprev = rp - step;
+                const uint8_t* rnext = rp + step;
+                const uint8_t* rnext2 = rnext + step;
+                r_patch[k] = w_tl * rp[0] + w_tr * rp[1] + w_bl * rnext[0] + w_br * rnext[1];
+                r_dx[k] = 0.5f * ((w_tl * rp[1] + w_tr * rp[2] + w_bl * rnext[1] + w_br * rnext[2]) -
+                                  (w_tl * rp[-1] + w_tr * rp[0] + w_bl * rnext[-1] + w_br * rnext[0]));
+                r_dy[k] = 0.5f * ((w_tl * rnext[0] + w_tr * rnext[1] + w_bl * rnext2[0] + w_br * rnext2[1]) -
+                                  (w_tl * rprev[0] + w_tr * rprev[1] + w_bl * rp[0] + w_br * rp[1]));
+                jvalid |= 1u << k;
+              }
+            }
+          }
+        }
+      }
+      if (tid == 0) {
+        double pose[16];
+        m4_mul(s_se3, s_last, pose);
+        for (int i = 0; i < 16; i++) s_pose[i] = pose[i];
+      }
+      __syncthreads();
+      // ------------------------------------------------ ComputeResiduals
+      double H[21], Jr[6];
+#pragma unroll
+      for (int i = 0; i < 21; i++) H[i] = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) Jr[i] = 0;
+      int nmeas = 0;
+#pragma unroll
+      for (int k = 0; k < AL_SLOTS; k++) {
+        const int p = tid + 256 * k;
+        const int pt = p >> 4, pix = p & 15;
+        float chi = 0.f;
+        if (pt < npts && s_vis[pt]) {
+          const double p0 = s_pts[pt * 3], p1 = s_pts[pt * 3 + 1], p2 = s_pts[pt * 3 + 2];
+          double xc[3];
+          for (int i = 0; i < 3; i++) xc[i] = (s_pose[i * 4] * p0 + s_pose[i * 4 + 1] * p1 + s_pose[i * 4 + 2] * p2) + s_pose[i * 4 + 3];
+          const double invzc = 1.0 / xc[2];
+          if (!(invzc < 0)) {
+            const double u2 = cam.fx * xc[0] * invzc + cam.cx;
+            const double v2 = cam.fy * xc[1] * invzc + cam.cy;
+            const float u_cur = (float)(u2 * scale);
+            const float v_cur = (float)(v2 * scale);
+            const int ui = (int)floorf(u_cur), vi = (int)floorf(v_cur);
+            if (!(ui < 0 || vi < 0 || ui - 3 < 0 || vi - 3 < 0 || ui + 3 >= cols || vi + 3 >= rows)) {
+              const float su = u_cur - ui, sv = v_cur - vi;
+              const float w_tl = (float)((1.0 - su) * (1.0 - sv));
+              const float w_tr = (float)(su * (1.0 - sv));
+              const float w_bl = (float)((1.0 - su) * sv);
+              const float w_br = (float)(su * sv);
+              const int y = vi - 2 + (pix >> 2), x = ui - 2 + (pix & 3);
+              const uint8_t* rp = img_cur + (size_t)y * step + x;
+              const uint8_t* rn = rp + step;
+              const float intensity = w_tl * rp[0] + w_tr * rp[1] + w_bl * rn[0] + w_br * rn[1];
+              const float res = intensity - r_patch[k];
+              chi = res * res * 1.0f;
+              nmeas++;
+              if (jvalid & (1u << k)) {
+                // Jacobian3DToPlane at the reference-frame point, then (dx*row0 + dy*row1)*(fx*scale)
+                const double X = s_xyz[pt * 3], Y = s_xyz[pt * 3 + 1];
+                const double z_inv = 1. / s_xyz[pt * 3 + 2];
+                const double z_inv_2 = z_inv * z_inv;
+                double J0[6], J1[6];
+                J0[0] = -z_inv; J0[1] = 0.0; J0[2] = X * z_inv_2; J0[3] = Y * J0[2]; J0[4] = -(1.0 + X * J0[2]); J0[5] = Y * z_inv;
+                J1[0] = 0.0; J1[1] = -z_inv; J1[2] = Y * z_inv_2; J1[3] = 1.0 + Y * J1[2]; J1[4] = -J0[3]; J1[5] = -X * z_inv;
+                double J[6];
+                const double ddx = r_dx[k], ddy = r_dy[k];
+#pragma unroll
+                for (int a = 0; a < 6; a++) J[a] = (ddx * J0[a] + ddy * J1[a]) * fscale;
+                int q = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                  for (int b = a; b < 6; b++) H[q++] += J[a] * J[b] * 1.0;
+                  Jr[a] -= J[a] * (double)res * 1.0;
+                }
+              }
+            }
+          }
+        }
+        if (p < AL_MAXP * 16) s_chi[p] = chi;
+      }
+      // fixed-shape reduction of the 27 sums + measurement count
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) H[i] += __shfl_xor(H[i], o);
+#pragma unroll
+        for (int i = 0; i < 6; i++) Jr[i] += __shfl_xor(Jr[i], o);
+        nmeas += __shfl_xor(nmeas, o);
+      }
+      if (lane == 0) {
+        for (int i = 0; i < 21; i++) s_red[wave][i] = H[i];
+        for (int i = 0; i < 6; i++) s_red[wave][21 + i] = Jr[i];
+        s_cnt[wave] = nmeas;
+      }
+      __syncthreads();
+      // ------------------------------------------------ Optimize (serial part)
+      if (tid == 0) {
+        iters[level] = it + 1;
+        double Hm[6][6], b[6], x[6];
+        int q = 0;
+        for (int a = 0; a < 6; a++)
+          for (int bb = a; bb < 6; bb++) {
+            double v = ((s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]));
+            Hm[a][bb] = v;
+            Hm[bb][a] = v;
+            q++;
+          }
+        for (int a = 0; a < 6; a++) b[a] = ((s_red[0][21 + a] + s_red[1][21 + a]) + (s_red[2][21 + a] + s_red[3][21 + a]));
+        const int n_meas = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        float chi2f = 0.0f;
+        const int npx = npts * 16;
+        for (int i = 0; i < npx; i++) chi2f += s_chi[i];
+        const double new_chi2 = (double)(chi2f / (float)n_meas);   // float/size_t -> float, then widened
+        if (n_meas == 0) stop_ = true;
+        ldlt_solve6(Hm, b, x);
+        if (isnan(x[0])) stop_ = true;
+        int brk = 0;
+        if ((it > 0 && new_chi2 > chi2_) || stop_) {
+          for (int i = 0; i < 16; i++) s_se3[i] = s_bk[i];
+          brk = 1;
+        } else {
+          if (it > 0 && new_chi2 > chi2_ * 0.99) small = true;
+          for (int i = 0; i < 16; i++) s_bk[i] = s_se3[i];
+          double nx[6], E[16], ns[16];
+          for (int i = 0; i < 6; i++) nx[i] = -x[i];
+          se3_exp(nx, E);
+          m4_mul(s_bk, E, ns);
+          for (int i = 0; i < 16; i++) s_se3[i] = ns[i];
+          chi2_ = new_chi2;
+          double mx = -1;
+          for (int i = 0; i < 6; i++)
+            if (fabs(x[i]) > mx) mx = fabs(x[i]);
+          error_ = mx;
+          if (error_ <= 1e-10 || small) brk = 1;
+        }
+        s_ctrl[0] = brk;
+      }
+      __syncthreads();
+      if (s_ctrl[0]) break;
+    }
+    // fast mode: "High error in max level means frames are not close, skip other levels"
+    if (tid == 0) {
+      int fail = 0;
+      if (mode == 2 && error_ > 0.01) { error_ = 1e10; ok = 0; fail = 1; }
+      if (mode == 3 && error_ > 0.03) { error_ = 1e10; ok = 0; fail = 1; }
+      s_ctrl[2] = fail;
+    }
+    __syncthreads();
+    if (s_ctrl[2]) break;
+  }
+  if (tid == 0) {
+    if (ok && mode != 3) {
+      double pose[16];
+      m4_mul(s_se3, s_last, pose);
+      for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) out_T[c * 4 + r] = pose[r * 4 + c];
+    }
+    tb.al_ok[f] = ok;
+    tb.al_err[f] = error_;
+    tb.al_chi2[f] = chi2_;
+    for (int l = 0; l < 16; l++) tb.al_iters[(size_t)f * 16 + l] = iters[l];
+  }
+}
+
+int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sf,
+                 const float* d_sf, int n_frames, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(k_align, dim3(n_frames), dim3(256), 0, s, cur->d_plan, cur->d_pyr, ref->d_pyr, tb, cam, d_inv_sf, d_sf, mode);
+  SD_HIP_CHECK(hipGetLastError());
+  return SD_OK;
+}
+
+}  // namespace sd

@@ -1,0 +1,63 @@
+// Internal structures of the sd_track handle (batched TrackWithMotionModel context).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orb_internal.h"
+
+namespace sd {
+
+// Device-resident per-frame arrays (frame index f selects a slice of each).
+struct TrackBuffers {
+  int max_points;        // capacity M of the last-frame arrays
+  int kp_cap;            // keypoint capacity of the current frame (extractor's nsel)
+  // last frame (LastFrame.mvpMapPoints flattened; index i == last-frame keypoint index)
+  uint8_t* valid;        // [B][M]   pMP != NULL && !mvbOutlier[i]
+  double* Xw;            // [B][M][3] pMP->GetWorldPos()
+  uint8_t* mp_desc;      // [B][M][32] pMP->GetDescriptor()
+  int32_t* octave;       // [B][M]   LastFrame.mvKeys[i].octave
+  float* angle;          // [B][M]   LastFrame.mvKeysUn[i].angle
+  int32_t* obs;          // [B][M]   pMP->Observations()
+  int32_t* n_last;       // [B]
+  // poses, 16 doubles column-major (Eigen::Matrix4d::data())
+  double* Tref;          // [B][16]  LastFrame.GetPose()
+  double* Tcur;          // [B][16]  CurrentFrame pose: in = prior, out = aligned / refined
+  // ImageAlign outputs
+  int32_t* al_ok;        // [B]
+  double* al_err;        // [B]  error_
+  double* al_chi2;       // [B]  chi2_
+  int32_t* al_iters;     // [B][16] iterations run per pyramid level
+  // SearchByProjection outputs
+  int32_t* cur_match;    // [B][kp_cap]  index into the last-frame arrays or -1
+  int32_t* n_matches;    // [B]
+  // PnP
+  int32_t* rand_stream;  // [B][4*pnp_max_its] raw rand() values
+  float* pnp_T;          // [B][16] row-major CV_32F 4x4
+  uint8_t* pnp_inliers;  // [B][kp_cap]
+  int32_t* pnp_info;     // [B][8]: ok, nInliers, noMore, iterations, N, minInliers, maxIts, refined
+  double* pnp_scratch;   // [B][kp_cap*12] EPnP per-correspondence work arrays (pws, us, alphas, pcs)
+};
+
+struct TrackCam {
+  double fx, fy, cx, cy;                 // (double)(float) like ImageAlign::cam_fx_
+  float ffx, ffy, fcx, fcy;              // Frame::fx ... (static floats)
+  float min_x, max_x, min_y, max_y;      // Frame::mnMinX ...
+  float bf, mb;                          // Frame::mbf, mb = mbf / fx
+};
+
+struct PnpParams {
+  double probability;
+  int min_inliers, max_iterations, min_set;
+  float epsilon, th2;
+  int n_iterations;     // argument of iterate()
+  int rand_per_frame;   // entries of rand_stream per frame
+};
+
+int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sf,
+                 const float* d_sf, int n_frames, int mode, hipStream_t s);
+int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, int n_frames, float th,
+                 int mono, int check_ori, hipStream_t s);
+int launch_pnp(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sigma2, const PnpParams& pp,
+               int n_frames, hipStream_t s);
+
+}  // namespace sd
