@@ -163,6 +163,10 @@ int sd_track_get_matches(sd_track* h, int frame0, int n_frames, int32_t* cur_mat
  * info8 = {returned(0/1), nInliers, bNoMore, iterations, N, minInliers, maxIts, refined} */
 int sd_track_get_pnp(sd_track* h, int frame0, int n_frames, float* Tcw_rowmajor, uint8_t* inliers,
                      int cap, int32_t* info8);
+/* diagnostics: device EPnP (PnPsolver::compute_pose, src/PnPsolver.cc:445-492) on n explicit
+ * correspondences; R9 row-major, returns the mean reprojection error in *reproj_err */
+int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy,
+                  double* R9, double* t3, double* reproj_err);
 int sd_track_set_profiling(sd_track* h, int on);
 int sd_track_stage_ms(sd_track* h, float* ms_out /* [0]=align, [1]=match */, int cap);
 

@@ -399,3 +399,15 @@ class Tracker:
         ms = np.zeros(2, np.float32)
         _check(self.L.sd_track_stage_ms(self.h, _p(ms), 2))
         return ms
+
+
+def debug_epnp(Xw, uv, K):
+    """Device EPnP on explicit correspondences (diagnostics)."""
+    L = lib()
+    L.sd_debug_epnp.argtypes = [C.c_int, C.c_void_p, C.c_void_p] + [C.c_double] * 4 + [C.c_void_p] * 3
+    Xw = np.ascontiguousarray(Xw, np.float64)
+    uv = np.ascontiguousarray(uv, np.float64)
+    R, t, e = np.zeros(9), np.zeros(3), C.c_double()
+    _check(L.sd_debug_epnp(len(Xw), _p(Xw), _p(uv), float(K[0]), float(K[1]), float(K[2]), float(K[3]), _p(R), _p(t),
+                           C.byref(e)))
+    return R.reshape(3, 3), t, e.value

@@ -284,6 +284,13 @@ int sd_track_get_pnp(sd_track* h, int frame0, int n_frames, float* Tcw_rowmajor,
   return SD_OK;
 }
 
+// EPnP (compute_pose, src/PnPsolver.cc:445-492) alone on explicit correspondences -- parity diagnostics
+int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy, double* R9, double* t3,
+                  double* reproj_err) {
+  SD_REQUIRE(n >= 4 && Xw && uv && R9 && t3, SD_ERR_INVALID_ARG, "bad arguments");
+  return run_epnp_debug(n, Xw, uv, fx, fy, cx, cy, R9, t3, reproj_err);
+}
+
 int sd_track_set_profiling(sd_track* h, int on) {
   SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
   h->profiling = on != 0;

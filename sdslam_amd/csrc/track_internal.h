@@ -60,4 +60,7 @@ int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam,
 int launch_pnp(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sigma2, const PnpParams& pp,
                int n_frames, hipStream_t s);
 
+int run_epnp_debug(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy, double* R9, double* t3,
+                   double* err);
+
 }  // namespace sd

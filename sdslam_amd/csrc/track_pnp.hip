@@ -12,12 +12,13 @@
 // refit, early return) is replayed in iteration order.  The refit EPnP (all best inliers) runs
 // on one lane.  OpenCV's cvSVD/cvSolve/cvInvert are restated as the same one-sided Jacobi
 // iteration order as OpenCV 3.2's JacobiSVDImpl_, so the 4-point (rank-deficient) null-space
-// bases agree with the oracle up to libm-level rounding of hypot().
+// bases agree with the oracle (hypot is the host libm's, restated in sd_hypot.h).
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
 
 #include "orb_internal.h"
+#include "sd_hypot.h"
 #include "track_internal.h"
 
 namespace sd {
@@ -49,7 +50,7 @@ __device__ void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int 
         for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
         if (fabs(p) <= eps * sqrt(a * b)) continue;
         p *= 2;
-        double beta = a - b, gamma = hypot(p, beta);
+        double beta = a - b, gamma = sdsc::hypot_glibc(p, beta);
         if (beta < 0) {
           double delta = (gamma - beta) * 0.5;
           s = sqrt(delta / gamma);
@@ -734,6 +735,36 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
       info[1] = best;
     }
   }
+}
+
+// diagnostics: EPnP alone on explicit correspondences (one lane)
+__global__ void k_epnp_debug(int n, const double* pws, const double* us, double* work, EpnpCam cam, double* out13) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double R[3][3], t[3];
+  double e = epnp_compute_pose(n, pws, us, work, work + 4 * (size_t)n, cam, R, t);
+  for (int i = 0; i < 9; i++) out13[i] = R[i / 3][i % 3];
+  for (int i = 0; i < 3; i++) out13[9 + i] = t[i];
+  out13[12] = e;
+}
+
+int run_epnp_debug(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy, double* R9, double* t3,
+                   double* err) {
+  double *d_p = nullptr, *d_u = nullptr, *d_w = nullptr, *d_o = nullptr;
+  SD_HIP_CHECK(hipMalloc(&d_p, sizeof(double) * 3 * n));
+  SD_HIP_CHECK(hipMalloc(&d_u, sizeof(double) * 2 * n));
+  SD_HIP_CHECK(hipMalloc(&d_w, sizeof(double) * 7 * n));
+  SD_HIP_CHECK(hipMalloc(&d_o, sizeof(double) * 13));
+  SD_HIP_CHECK(hipMemcpy(d_p, Xw, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+  SD_HIP_CHECK(hipMemcpy(d_u, uv, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+  EpnpCam cam = {fx, fy, cx, cy};
+  hipLaunchKernelGGL(k_epnp_debug, dim3(1), dim3(64), 0, 0, n, d_p, d_u, d_w, cam, d_o);
+  double out[13];
+  SD_HIP_CHECK(hipMemcpy(out, d_o, sizeof(out), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 9; i++) R9[i] = out[i];
+  for (int i = 0; i < 3; i++) t3[i] = out[9 + i];
+  if (err) *err = out[12];
+  (void)hipFree(d_p); (void)hipFree(d_u); (void)hipFree(d_w); (void)hipFree(d_o);
+  return SD_OK;
 }
 
 int launch_pnp(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sigma2, const PnpParams& pp,

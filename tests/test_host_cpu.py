@@ -130,3 +130,10 @@ def test_sincosf_restatement_matches_host_libm_sampled():
     out = subprocess.run([exe, "257"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "sin mismatches 0, cos mismatches 0" in out.stdout
+
+
+def test_hypot_restatement_matches_host_libm_sampled():
+    exe = "/tmp/sd_check_hypot"
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tools", "check_hypot.cc"), "-o", exe, "-lm"])
+    out = subprocess.run([exe, "5000000"], capture_output=True, text=True)
+    assert out.returncode == 0 and "hypot mismatches 0" in out.stdout, out.stdout
