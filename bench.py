@@ -3,15 +3,20 @@
 
     python bench.py --gpus N --steps K --warmup W [--batch B]
 
-A "step" is one pass of the hot path over one batch of B synthetic 640x480 frames that are
-already resident in HBM (the batched-frames mode of SURVEY.md §8e).  With N > 1 the driver
-launches one rank per GPU (torch.distributed / RCCL); frames are independent, so ranks share
-nothing on the data path (weak scaling) and only the fixed-size per-frame result records are
-all-gathered.  Rank 0 prints ONE JSON line.
+Workload (BASELINE.json metric: "tracked frames/sec (ORB+ImageAlign+PnP) at 640x480, 1000 kp"):
+one *step* tracks a batch of B independent 640x480 frames, all resident in HBM:
+    ORB extract (8 levels x1.2, 1000 kp)  ->  ImageAlign (levels 4,3,2, <=30 GN its each)
+    ->  SearchByProjection (th 8, mono, orientation check)  ->  PnP RANSAC (<=200 its, EPnP)
+i.e. the TrackWithMotionModel sequence of SURVEY.md §3.2 / config C4.  The last frames'
+pyramids, map points and the predicted poses are set up (untimed) beforehand, exactly as they
+would be left behind by the previous tracking step.  With N > 1 the driver launches one rank
+per GPU (torch.distributed / RCCL); frames are independent, so ranks share nothing on the data
+path (weak scaling); the fixed-size per-frame pose records are all-gathered once.
+Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
   roofline     -- the dominant kernel stage: algorithmic bytes per launch / its mean
-                  duration measured with HIP events on the launch stream inside the timed region
+                  duration, measured with HIP events on the launch stream inside the timed region
   cpu_baseline -- the CPU oracle (a port of the reference path; the reference itself needs
                   OpenCV/Eigen and cannot be built here) timed on this host, 1 core, bounded sample
 """
@@ -27,24 +32,68 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+CFG = (1000, 1.2, 8, 20)
+W, H = 640, 480
+BOUNDS = (0.0, 640.0, 0.0, 480.0)
+PNP = dict(probability=0.99, min_inliers=10, max_iterations=200, min_set=4, epsilon=0.28, th2=5.991)
 
 
-def cpu_baseline(images, cfg, budget_s=12.0):
-    """Oracle (-O3 -march=native build) on the host cores of this box: 1 thread, bounded sample."""
+def make_cases(n_unique, seed0):
+    """n_unique two-view scenes with slightly different motions."""
+    from sdslam_amd import synth
+    rng = np.random.default_rng(seed0)
+    scenes = []
+    for i in range(n_unique):
+        ups = np.array([0.02, -0.01, 0.015]) + rng.normal(size=3) * 0.004
+        om = np.array([0.4, -0.3, 0.5]) + rng.normal(size=3) * 0.1
+        scenes.append(synth.make_scene(seed0 + i, tuple(ups), tuple(om)))
+    return scenes
+
+
+def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0):
+    """The oracle's full tracking step (-O3 -march=native build) on this host: 1 thread."""
     from oracle import oracle as O
-    ora = O.OrbOracle(*cfg, fast_build=True)
-    ora.extract(images[0])   # warm
+    from sdslam_amd import synth
+    K = (synth.FX, synth.FY, synth.CX, synth.CY)
+    O.lib(True)
+    ora_ref = [O.OrbOracle(*CFG, fast_build=True) for _ in scenes]
+    for o, s in zip(ora_ref, scenes):
+        o.extract(s["ref"])
+    ref_pyr = [[o.level(l) for l in range(CFG[2])] for o in ora_ref]
+    cur = O.OrbOracle(*CFG, fast_build=True)
+    tab = cur.tables()
     t0 = time.perf_counter()
     n = 0
+    t_stage = np.zeros(4)
     while True:
-        ora.extract(images[n % len(images)])
+        i = n % len(scenes)
+        s, last = scenes[i], lasts[i]
+        ta = time.perf_counter()
+        ck, cd = cur.extract(s["cur"])
+        tb = time.perf_counter()
+        pc = [cur.level(l) for l in range(CFG[2])]
+        tb2 = time.perf_counter()
+        r = O.align(pc, ref_pyr[i], tab["inv_sf"], tab["sf"], last["Xw"][last["valid"] != 0], s["T_ref"], T0s[i], K, 0)
+        tc = time.perf_counter()
+        nm, cm = O.search_by_projection(ck, cd, tab["sf"], BOUNDS, K, r["T"], s["T_ref"], last, th=8.0)
+        td = time.perf_counter()
+        valid = (cm >= 0).astype(np.uint8)
+        Xw = np.zeros((len(ck), 3))
+        Xw[valid != 0] = last["Xw"][cm[valid != 0]]
+        p = O.PnPOracle(valid, np.stack([ck["x"], ck["y"]], 1), ck["octave"], tab["sigma2"], Xw, K)
+        p.set_ransac(PNP["probability"], PNP["min_inliers"], PNP["max_iterations"], 4, PNP["epsilon"], PNP["th2"])
+        p.iterate(PNP["max_iterations"], rs)
+        te = time.perf_counter()
+        t_stage += [tb - ta, tc - tb2, td - tc, te - td]
         n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 2000:
+        if time.perf_counter() - t0 > budget_s or n >= 1000:
             break
-    dt = time.perf_counter() - t0
+    dt = t_stage.sum()      # excludes the Python-side pyramid copies between the C calls
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} VGA frames, ORB extract (8 levels x1.2, 1000 kp), 1 thread, "
-                      f"{os.cpu_count()} host cpus visible"}
+            "sample": f"{n} VGA frame pairs, full step (ORB extract + ImageAlign + SearchByProjection + PnP RANSAC), "
+                      f"1 thread of {os.cpu_count()} host cpus",
+            "ms_per_frame": {"orb_extract": t_stage[0] / n * 1e3, "image_align": t_stage[1] / n * 1e3,
+                             "search_by_projection": t_stage[2] / n * 1e3, "pnp_ransac": t_stage[3] / n * 1e3}}
 
 
 def main():
@@ -53,8 +102,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames (tiled to --batch)")
+    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic scenes (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--orb-only", action="store_true", help="time ORB extraction alone (configs[1] without tracking)")
     args = ap.parse_args()
 
     import torch
@@ -62,30 +112,50 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
 
     import sdslam_amd
+    from sdslam_amd import synth
     from sdslam_amd.capi import DeviceBuffer
-    from sdslam_amd.synth import make_image
 
-    W, H, B = 640, 480, args.batch
-    cfg = (1000, 1.2, 8, 20)          # BASELINE configs[1]: 8-level pyramid, 1000 kp
-    uniq = [make_image(10_000 * rank + i, W, H) for i in range(min(args.unique, B))]
-    frames = np.stack([uniq[i % len(uniq)] for i in range(B)])
-    dbuf = DeviceBuffer(frames.nbytes)
-    dbuf.upload(frames)
+    B = args.batch
+    K = (synth.FX, synth.FY, synth.CX, synth.CY)
+    nu = max(1, min(args.unique, B))
+    scenes = make_cases(nu, 1000 + 100 * rank)
+    idx = [i % nu for i in range(B)]
+    cur_frames = np.stack([scenes[i]["cur"] for i in idx])
+    ref_frames = np.stack([scenes[i]["ref"] for i in idx])
+    d_cur = DeviceBuffer(cur_frames.nbytes)
+    d_cur.upload(cur_frames)
 
-    ext = sdslam_amd.ORBextractor(*cfg, W, H, B, device=local_rank)
+    cur = sdslam_amd.ORBextractor(*CFG, W, H, B, device=local_rank)
+    ref = sdslam_amd.ORBextractor(*CFG, W, H, B, device=local_rank)
+    trk = sdslam_amd.Tracker(cur, ref, max_points=1000, max_batch=B, pnp_max_iterations=PNP["max_iterations"])
+    trk.set_camera(*K, 0.0, BOUNDS)
+
+    # ---- untimed setup: what the previous tracking step leaves behind
+    rk, rd, rn = ref.extract_batch(ref_frames)                       # last frames' pyramids stay resident
+    lasts_u = [synth.tracking_case(i, rk[i, :rn[i]], rd[i, :rn[i]]) for i in range(nu)]
+    trk.set_last(0, [lasts_u[i] for i in idx])
+    pert = synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04))   # motion-model prediction error
+    T0_u = [pert @ s["T_cur"] for s in scenes]
+    T_ref = [scenes[i]["T_ref"] for i in idx]
+    T0 = [T0_u[i] for i in idx]
+    rs = synth.glibc_rand_stream(4 * PNP["max_iterations"])
+    trk.set_rand(0, np.tile(rs, (B, 1)))
 
     def step():
-        ext.extract_batch_device(dbuf.ptr, B, W, H)
+        cur.extract_batch_device(d_cur.ptr, B, W, H)
+        if not args.orb_only:
+            trk.align(B, 0)
+            trk.match(B, 8.0, True, True)
+            trk.pnp(B, PNP["probability"], PNP["min_inliers"], PNP["max_iterations"], PNP["min_set"], PNP["epsilon"],
+                    PNP["th2"], PNP["max_iterations"])
 
     def barrier():
         torch.cuda.synchronize()
@@ -93,56 +163,77 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trk.set_poses(0, T_ref, T0)         # last-frame poses + motion-model predictions (resident, like the frames)
     for _ in range(args.warmup):
         step()
-    ext.sync()
-    ext.set_profiling(True)           # HIP events around each stage, on the launch stream
+    cur.sync()
+    cur.set_profiling(True)
+    trk.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step()                          # every step re-aligns from the predicted pose (Tprior is not overwritten)
     barrier()
     dt = time.perf_counter() - t0
-    stage_ms = ext.stage_ms()         # mean per stage over the timed steps
-    ext.set_profiling(False)
+    orb_ms = cur.stage_ms()
+    trk_ms = trk.stage_ms() if not args.orb_only else np.zeros(3, np.float32)
+    cur.set_profiling(False)
+    trk.set_profiling(False)
 
-    # pose/result records of all ranks (fixed-size; the only inter-GPU traffic)
-    kps, desc, n = ext.download(0, min(B, 4))
+    # ---- results: fixed-size per-frame records (pose + counts), all-gathered across ranks
+    al = trk.get_align(0, B)
+    pn = trk.get_pnp(0, B)
+    cm, nm = trk.get_matches(0, B)
+    rec = np.zeros((B, 20), np.float64)
+    rec[:, :16] = np.stack([t.T.ravel() for t in al["T"]])
+    rec[:, 16], rec[:, 17], rec[:, 18], rec[:, 19] = al["ok"], nm, pn["n_inliers"], pn["ok"]
     if dist is not None:
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        rec = torch.from_numpy(n.astype(np.int32)).cuda()
-        out = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(out, rec)
+        r = torch.from_numpy(rec).cuda()
+        out = [torch.empty_like(r) for _ in range(world)]
+        dist.all_gather(out, r)
 
     if rank == 0:
         total_frames = B * args.steps * world
-        names = ext.stage_names()
-        sbytes = ext.stage_bytes()
+        names = cur.stage_names() + ["image_align", "search_by_projection", "pnp_ransac"]
+        stage_ms = np.concatenate([orb_ms, trk_ms])
+        sbytes = list(cur.stage_bytes())
+        # algorithmic bytes of the tracking stages, from what this run actually did
+        P = float(np.mean([min(300, int(l["valid"].sum())) for l in lasts_u]))
+        its = float(al["iters"][:, :8].sum(axis=1).mean())
+        lv = sdslam_amd.plan_info(*CFG, W, H)["levels"]
+        px_l = float(sum(lv[l, 0] * lv[l, 1] for l in (2, 3, 4)))
+        sbytes += [its * P * (25 + 64) + 2 * px_l,                       # ImageAlign
+                   P * (32 + 10 * 32),                                   # windowed Hamming (c ~ 10)
+                   float(pn["iterations"].mean()) * (4 * 20 + float(pn["N"].mean()) * 24)]   # PnP
         dom = int(np.argmax(stage_ms))
-        launches = {"pyramid": cfg[2]}.get(names[dom], 1)
         achieved = sbytes[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
+        terr = float(np.mean([np.abs(al["T"][b][:3, 3] - scenes[idx[b]]["T_cur"][:3, 3]).max() for b in range(min(B, nu))]))
         line = {
             "metric": "tracked frames/sec (ORB+ImageAlign+PnP) at 640x480, 1000 kp",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 640x480, 8-level x1.2 pyramid, 1000 kp, ORB extract "
-                                   "(stages so far: pyramid, FAST+NMS, select, blur, orientation+rBRIEF)",
-                       "frames_per_gpu_per_step": B, "unique_frames": len(uniq), "inputs": "resident in HBM"},
-            "stages_ms_per_step": {nm: float(ms) for nm, ms in zip(names, stage_ms)},
+            "config": {"workload": ("ORB extract only (BASELINE configs[1] without matching)" if args.orb_only else
+                                    "BASELINE configs[3] at the configs[1] pyramid: 640x480, 8-level x1.2, 1000 kp; "
+                                    "ORB extract + ImageAlign (levels 4,3,2) + SearchByProjection + PnP RANSAC 200 its"),
+                       "frames_per_gpu_per_step": B, "unique_scenes": nu, "inputs": "resident in HBM",
+                       "pose_records": "all-gathered over RCCL" if world > 1 else "single GPU"},
+            "stages_ms_per_step": {nm_: float(ms) for nm_, ms in zip(names, stage_ms)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_frame": float(sbytes[dom]), "launches_per_step": launches,
-                         "ms_per_step": float(stage_ms[dom])},
-            "keypoints_first_frames": [int(x) for x in n],
+                         "algorithmic_bytes_per_frame": float(sbytes[dom]), "ms_per_step": float(stage_ms[dom])},
+            "tracking": {"align_ok": int(al["ok"].sum()), "mean_gn_iterations": its, "mean_matches": float(nm.mean()),
+                         "pnp_ok": int(pn["ok"].sum()), "mean_pnp_inliers": float(pn["n_inliers"].mean()),
+                         "mean_pnp_iterations": float(pn["iterations"].mean()), "align_translation_err_m": terr},
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(uniq, cfg)
+        if not args.no_cpu_baseline and world == 1 and not args.orb_only:
+            line["cpu_baseline"] = cpu_baseline(scenes, lasts_u, T0_u, rs)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        print(json.dumps(line, default=float))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -152,7 +152,9 @@ int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori)
 int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers, int max_iterations,
                  int min_set, float epsilon, float th2, int n_iterations);
 
-/* ImageAlign results: pose written by CurrentFrame.SetPose (unchanged when ok == 0 or mode 3),
+/* sd_track_set_poses: LastFrame.GetPose() and the current frame's prior pose (motion-model
+ * prediction); sd_track_align reads the prior and leaves the aligned pose for the later stages.
+ * ImageAlign results: pose written by CurrentFrame.SetPose (= the prior when ok == 0 or mode 3),
  * GetError(), the bool return, iterations per pyramid level (n x 16) and chi2_ */
 int sd_track_get_align(sd_track* h, int frame0, int n_frames, double* Tcur_cm, double* error,
                        int32_t* ok, int32_t* iters, double* chi2);
@@ -168,7 +170,7 @@ int sd_track_get_pnp(sd_track* h, int frame0, int n_frames, float* Tcw_rowmajor,
 int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy,
                   double* R9, double* t3, double* reproj_err);
 int sd_track_set_profiling(sd_track* h, int on);
-int sd_track_stage_ms(sd_track* h, float* ms_out /* [0]=align, [1]=match */, int cap);
+int sd_track_stage_ms(sd_track* h, float* ms_out /* [0]=align, [1]=match, [2]=pnp */, int cap);
 
 /* ------------------------------------------------------------------------------------------
  * ORBmatcher::DescriptorDistance -- src/ORBmatcher.h:44, src/ORBmatcher.cc:1459-1473

@@ -396,8 +396,8 @@ class Tracker:
         _check(self.L.sd_track_set_profiling(self.h, int(on)))
 
     def stage_ms(self):
-        ms = np.zeros(2, np.float32)
-        _check(self.L.sd_track_stage_ms(self.h, _p(ms), 2))
+        ms = np.zeros(3, np.float32)
+        _check(self.L.sd_track_stage_ms(self.h, _p(ms), 3))
         return ms
 
 

@@ -29,11 +29,10 @@ struct sd_track {
   float* d_sf = nullptr;
   float* d_inv_sf = nullptr;
   float* d_sigma2 = nullptr;
-  hipStream_t stream = nullptr;
   std::vector<void*> allocs;
   bool profiling = false;
   static const int kRing = 128;
-  hipEvent_t ev[kRing][4] = {};
+  hipEvent_t ev[kRing][6] = {};
   int ev_calls[3] = {0, 0, 0};
 };
 
@@ -69,7 +68,6 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   h->max_batch = max_batch;
   h->kp_cap = nsel;
   h->device = cur->device;
-  h->stream = cur->stream;
   h->rand_per_frame = 4 * pnp_max_iterations;
   const size_t B = max_batch, M = max_points, K = nsel;
   TrackBuffers& tb = h->tb;
@@ -85,6 +83,7 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.obs, B * M));
   A(dalloc(h, &tb.n_last, B));
   A(dalloc(h, &tb.Tref, B * 16));
+  A(dalloc(h, &tb.Tprior, B * 16));
   A(dalloc(h, &tb.Tcur, B * 16));
   A(dalloc(h, &tb.al_ok, B));
   A(dalloc(h, &tb.al_err, B));
@@ -105,7 +104,7 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
     if (e == hipSuccess) e = hipMemcpy(h->d_inv_sf, cur->hp.inv_sf.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_sigma2, cur->hp.sigma2.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
     for (int r = 0; r < sd_track::kRing && e == hipSuccess; r++)
-      for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
+      for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
     if (e != hipSuccess) {
       set_error(std::string("sd_track_create: ") + hipGetErrorString(e));
       rc = SD_ERR_HIP;
@@ -122,10 +121,10 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
 void sd_track_destroy(sd_track* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->cur && h->cur->stream) (void)hipStreamSynchronize(h->cur->stream);
   for (void* p : h->allocs) (void)hipFree(p);
   for (int r = 0; r < sd_track::kRing; r++)
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 6; i++)
       if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
   delete h;
 }
@@ -155,7 +154,7 @@ int sd_track_set_last(sd_track* h, int frame0, int n_frames, const int32_t* n_la
   SD_REQUIRE(n_last && valid && Xw && desc && octave && angle && obs, SD_ERR_INVALID_ARG, "NULL argument");
   const size_t M = h->max_points, o = (size_t)frame0;
   for (int f = 0; f < n_frames; f++) SD_REQUIRE(n_last[f] >= 0 && n_last[f] <= h->max_points, SD_ERR_CAPACITY, "n_last exceeds max_points");
-  hipStream_t s = h->stream;
+  hipStream_t s = h->cur->stream;
   const TrackBuffers& tb = h->tb;
   SD_HIP_CHECK(hipMemcpyAsync(tb.n_last + o, n_last, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
   SD_HIP_CHECK(hipMemcpyAsync(tb.valid + o * M, valid, n_frames * M, hipMemcpyHostToDevice, s));
@@ -171,9 +170,11 @@ int sd_track_set_last(sd_track* h, int frame0, int n_frames, const int32_t* n_la
 int sd_track_set_poses(sd_track* h, int frame0, int n_frames, const double* Tref_cm, const double* Tcur_cm) {
   TRACK_RANGE(h, frame0, n_frames);
   SD_REQUIRE(Tref_cm && Tcur_cm, SD_ERR_INVALID_ARG, "NULL argument");
-  SD_HIP_CHECK(hipMemcpyAsync(h->tb.Tref + (size_t)frame0 * 16, Tref_cm, (size_t)n_frames * 128, hipMemcpyHostToDevice, h->stream));
-  SD_HIP_CHECK(hipMemcpyAsync(h->tb.Tcur + (size_t)frame0 * 16, Tcur_cm, (size_t)n_frames * 128, hipMemcpyHostToDevice, h->stream));
-  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  hipStream_t s = h->cur->stream;
+  SD_HIP_CHECK(hipMemcpyAsync(h->tb.Tref + (size_t)frame0 * 16, Tref_cm, (size_t)n_frames * 128, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(h->tb.Tprior + (size_t)frame0 * 16, Tcur_cm, (size_t)n_frames * 128, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(h->tb.Tcur + (size_t)frame0 * 16, Tcur_cm, (size_t)n_frames * 128, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
   return SD_OK;
 }
 
@@ -181,8 +182,8 @@ int sd_track_set_rand(sd_track* h, int frame0, int n_frames, const int32_t* rand
   TRACK_RANGE(h, frame0, n_frames);
   SD_REQUIRE(rand_values && per_frame >= 1 && per_frame <= h->rand_per_frame, SD_ERR_INVALID_ARG, "bad rand stream");
   SD_HIP_CHECK(hipMemcpy2DAsync(h->tb.rand_stream + (size_t)frame0 * h->rand_per_frame, (size_t)h->rand_per_frame * 4, rand_values,
-                                (size_t)per_frame * 4, (size_t)per_frame * 4, n_frames, hipMemcpyHostToDevice, h->stream));
-  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+                                (size_t)per_frame * 4, (size_t)per_frame * 4, n_frames, hipMemcpyHostToDevice, h->cur->stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->cur->stream));
   return SD_OK;
 }
 
@@ -192,11 +193,6 @@ static int check_ready(sd_track* h, int n_frames) {
   SD_REQUIRE(n_frames >= 1 && n_frames <= h->max_batch, SD_ERR_CAPACITY, "n_frames exceeds max_batch");
   SD_REQUIRE(h->cur->have_geom && h->cur->last_frames >= n_frames, SD_ERR_INVALID_ARG, "current frames have not been extracted");
   SD_HIP_CHECK(hipSetDevice(h->device));
-  return SD_OK;
-}
-
-static int prof_begin(sd_track* h, int which) {
-  if (h->profiling) SD_HIP_CHECK(hipEventRecord(h->ev[h->ev_calls[which] % sd_track::kRing][which == 0 ? 0 : which], h->cur->stream));
   return SD_OK;
 }
 
@@ -242,7 +238,12 @@ int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers,
   pp.th2 = th2;
   pp.n_iterations = n_iterations;
   pp.rand_per_frame = h->rand_per_frame;
-  return launch_pnp(h->cur, h->tb, h->cam, h->d_sigma2, pp, n_frames, h->cur->stream);
+  hipStream_t s = h->cur->stream;
+  hipEvent_t* ev = h->ev[h->ev_calls[2] % sd_track::kRing];
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[4], s));
+  rc = launch_pnp(h->cur, h->tb, h->cam, h->d_sigma2, pp, n_frames, s);
+  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[5], s)); h->ev_calls[2]++; }
+  return rc;
 }
 
 int sd_track_get_align(sd_track* h, int frame0, int n_frames, double* Tcur_cm, double* error, int32_t* ok, int32_t* iters,
@@ -298,13 +299,13 @@ int sd_track_set_profiling(sd_track* h, int on) {
   return SD_OK;
 }
 
-// mean ms of the align and match launches since profiling was switched on: ms_out[0] = align, [1] = match
+// mean ms of the align / match / pnp launches since profiling was switched on
 int sd_track_stage_ms(sd_track* h, float* ms_out, int cap) {
-  SD_REQUIRE(h && ms_out && cap >= 2, SD_ERR_INVALID_ARG, "bad arguments");
+  SD_REQUIRE(h && ms_out && cap >= 3, SD_ERR_INVALID_ARG, "bad arguments");
   SD_REQUIRE(h->profiling, SD_ERR_INVALID_ARG, "profiling is off");
   SD_HIP_CHECK(hipSetDevice(h->device));
   SD_HIP_CHECK(hipStreamSynchronize(h->cur->stream));
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < 3; k++) {
     ms_out[k] = 0;
     const int n = std::min(h->ev_calls[k], (int)sd_track::kRing);
     for (int r = 0; r < n; r++) {

@@ -189,8 +189,10 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
   for (int i = tid; i < AL_MAXP; i += 256) s_vis[i] = 0;
 
   double* out_T = tb.Tcur + (size_t)f * 16;
+  const double* prior_T = tb.Tprior + (size_t)f * 16;
   if (P->nlevels <= 4 || npts == 0) {   // "Not enough pyramid levels" / "No points to track!"
     if (tid == 0) {
+      for (int i = 0; i < 16; i++) out_T[i] = prior_T[i];
       tb.al_ok[f] = 0;
       tb.al_err[f] = 1e10;
       tb.al_chi2[f] = 1e10;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
     for (int c = 0; c < 4; c++)
       for (int r = 0; r < 4; r++) {
         last[r * 4 + c] = tb.Tref[(size_t)f * 16 + c * 4 + r];
-        cur[r * 4 + c] = out_T[c * 4 + r];
+        cur[r * 4 + c] = prior_T[c * 4 + r];
       }
     for (int i = 0; i < 16; i++) s_last[i] = last[i];
     if (mode == 3) {
@@ -440,6 +442,8 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
       m4_mul(s_se3, s_last, pose);
       for (int c = 0; c < 4; c++)
         for (int r = 0; r < 4; r++) out_T[c * 4 + r] = pose[r * 4 + c];
+    } else {
+      for (int i = 0; i < 16; i++) out_T[i] = prior_T[i];   // pose left as it was (src/Tracking.cc:669-672)
     }
     tb.al_ok[f] = ok;
     tb.al_err[f] = error_;

@@ -21,7 +21,8 @@ struct TrackBuffers {
   int32_t* n_last;       // [B]
   // poses, 16 doubles column-major (Eigen::Matrix4d::data())
   double* Tref;          // [B][16]  LastFrame.GetPose()
-  double* Tcur;          // [B][16]  CurrentFrame pose: in = prior, out = aligned / refined
+  double* Tprior;        // [B][16]  CurrentFrame pose before alignment (motion-model prediction)
+  double* Tcur;          // [B][16]  CurrentFrame pose after ImageAlign (= Tprior when it returns false)
   // ImageAlign outputs
   int32_t* al_ok;        // [B]
   double* al_err;        // [B]  error_

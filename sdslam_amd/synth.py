@@ -124,3 +124,26 @@ def tracking_case(seed: int, ref_kps, ref_desc, max_points=300, **kw):
     Xw = backproject_on_surface(np.stack([ref_kps["x"], ref_kps["y"]], 1))
     return dict(valid=valid, Xw=Xw, desc=ref_desc.copy(), octave=ref_kps["octave"].astype(np.int32).copy(),
                 angle=ref_kps["angle"].astype(np.float32).copy(), obs=np.ones(n, np.int32))
+
+
+def glibc_rand_stream(n, seed=1):
+    """n raw rand() values of glibc's TYPE_3 additive-feedback generator seeded with `seed`.
+    The reference never seeds: SD_SLAM::Random draws from the default seed-1 state (reference
+    src/extra/utils.cc:23-26).  Restated so harnesses do not perturb the process RNG."""
+    r = [0] * 34
+    r[0] = seed
+    for i in range(1, 31):
+        hi, lo = divmod(r[i - 1], 127773)
+        w = 16807 * lo - 2836 * hi
+        if w < 0:
+            w += 2147483647
+        r[i] = w
+    for i in range(31, 34):
+        r[i] = r[i - 31]
+    out = []
+    for i in range(34, 344 + n):
+        v = (r[i - 31] + r[i - 3]) & 0xFFFFFFFF
+        r.append(v)
+        if i >= 344:
+            out.append(v >> 1)
+    return np.array(out, np.int32)
