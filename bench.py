@@ -184,16 +184,12 @@ def main():
     al = trk.get_align(0, B)
     pn = trk.get_pnp(0, B)
     cm, nm = trk.get_matches(0, B)
-    rec = np.zeros((B, 20), np.float64)
-    rec[:, :16] = np.stack([t.T.ravel() for t in al["T"]])
-    rec[:, 16], rec[:, 17], rec[:, 18], rec[:, 19] = al["ok"], nm, pn["n_inliers"], pn["ok"]
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        r = torch.from_numpy(rec).cuda()
-        out = [torch.empty_like(r) for _ in range(world)]
-        dist.all_gather(out, r)
+    from sdslam_amd import dist_util
+    rec = dist_util.pack_records([t.T.ravel() for t in al["T"]], al["ok"], nm, pn["n_inliers"], pn["ok"])
+    dev = torch.device("cuda", local_rank)
+    dt = dist_util.max_over_ranks(dt, dist, dev)                      # MAX over ranks
+    all_rec = dist_util.gather_records(rec, B * world, dist, dev)     # the only inter-GPU traffic
+    assert all_rec.shape == (B * world, dist_util.RECORD_F64)
 
     if rank == 0:
         total_frames = B * args.steps * world

@@ -1,0 +1,211 @@
+// sdslam.hpp -- header-only C++ facade over the C ABI (sdslam_hip.h) that re-exposes the
+// reference's class and method names for the tracking hot path, over POD types that are
+// layout-compatible with what the reference's callers hold:
+//   SD_SLAM::KeyPoint   == cv::KeyPoint (28 bytes)
+//   descriptors         == N x 32 uint8 row-major (cv::Mat CV_8U)
+//   poses               == 16 doubles column-major (Eigen::Matrix4d::data())
+// A reference translation unit (Frame.cc / Tracking.cc style) keeps its call sites; see
+// INTEGRATION.md for the type-alias header that maps cv::Mat / Eigen arguments onto these.
+//
+//   ORBextractor   reference src/ORBextractor.h:38-70
+//   ORBmatcher     reference src/ORBmatcher.h:40-52  (DescriptorDistance, SearchByProjection(Frame,Frame))
+//   ImageAlign     reference src/ImageAlign.h:32-44  (ComputePose, GetError)
+//   PnPsolver      reference src/PnPsolver.h:67-76   (SetRansacParameters, iterate)
+// ImageAlign / ORBmatcher / PnPsolver operate on a TrackBatch (frames resident on the GPU).
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../sdslam_hip.h"
+
+namespace SD_SLAM {
+
+typedef sd_keypoint KeyPoint;
+static_assert(sizeof(KeyPoint) == 28, "cv::KeyPoint layout");
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+inline void check(int rc) {
+  if (rc != SD_OK) throw Error(rc, sd_last_error());
+}
+
+// Image pyramid level as handed back by ORBextractor::operator() (host copy on demand).
+struct Mat8 {
+  int cols = 0, rows = 0;
+  std::vector<uint8_t> data;
+  const uint8_t* ptr(int y) const { return data.data() + (size_t)y * cols; }
+};
+
+class ORBextractor {
+ public:
+  enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int thFAST, int max_w = 1280, int max_h = 960, int max_batch = 1,
+               int device = 0)
+      : nlevels_(nlevels), scaleFactor_(scaleFactor), cap_(nfeatures) {
+    check(sd_orb_create(nfeatures, scaleFactor, nlevels, thFAST, max_w, max_h, max_batch, device, &h_));
+  }
+  ~ORBextractor() { sd_orb_destroy(h_); }
+  ORBextractor(const ORBextractor&) = delete;
+  ORBextractor& operator=(const ORBextractor&) = delete;
+
+  // operator()(image, mask, keypoints, descriptors, imagePyramid); mask is ignored like in the
+  // reference.  `image` is an 8-bit single-channel buffer (cv::Mat::data / step).
+  void operator()(const uint8_t* image, int cols, int rows, int step, std::vector<KeyPoint>& keypoints,
+                  std::vector<uint8_t>& descriptors, std::vector<Mat8>* imagePyramid = nullptr) {
+    keypoints.resize(cap_);
+    descriptors.resize((size_t)cap_ * 32);
+    int n = 0;
+    check(sd_orb_extract(h_, image, cols, rows, step, keypoints.data(), descriptors.data(), cap_, &n));
+    keypoints.resize(n);
+    descriptors.resize((size_t)n * 32);
+    if (imagePyramid && cols > 0 && rows > 0) {
+      imagePyramid->resize(nlevels_);
+      for (int l = 0; l < nlevels_; l++) {
+        Mat8& m = (*imagePyramid)[l];
+        check(sd_orb_level_info(h_, l, &m.cols, &m.rows));
+        m.data.resize((size_t)m.cols * m.rows);
+        check(sd_orb_level_copy(h_, 0, l, 0, m.data.data(), m.cols));
+      }
+    }
+  }
+
+  int GetLevels() { return nlevels_; }
+  float GetScaleFactor() { return scaleFactor_; }
+  std::vector<float> GetScaleFactors() { return table(0); }
+  std::vector<float> GetInverseScaleFactors() { return table(1); }
+  std::vector<float> GetScaleSigmaSquares() { return table(2); }
+  std::vector<float> GetInverseScaleSigmaSquares() { return table(3); }
+
+  sd_orb* handle() { return h_; }
+
+ private:
+  std::vector<float> table(int which) {
+    std::vector<float> t[4];
+    for (auto& v : t) v.resize(nlevels_);
+    check(sd_orb_scale_tables(h_, t[0].data(), t[1].data(), t[2].data(), t[3].data()));
+    return t[which];
+  }
+  sd_orb* h_ = nullptr;
+  int nlevels_;
+  float scaleFactor_;
+  int cap_;
+};
+
+// Flattened view of what TrackWithMotionModel reads from LastFrame (src/Tracking.cc:654-718):
+// one entry per last-frame keypoint.
+struct LastFrameView {
+  std::vector<uint8_t> valid;    // mvpMapPoints[i] != NULL && !mvbOutlier[i]
+  std::vector<double> Xw;        // 3 per entry: pMP->GetWorldPos()
+  std::vector<uint8_t> desc;     // 32 per entry: pMP->GetDescriptor()
+  std::vector<int32_t> octave;   // mvKeys[i].octave
+  std::vector<float> angle;      // mvKeysUn[i].angle
+  std::vector<int32_t> obs;      // pMP->Observations()
+  int size() const { return (int)valid.size(); }
+};
+
+// One batch of (current frame, last frame) pairs resident on the GPU.
+class TrackBatch {
+ public:
+  TrackBatch(ORBextractor& cur, ORBextractor& ref, int max_points, int max_batch, int pnp_max_iterations = 300)
+      : max_points_(max_points) {
+    check(sd_track_create(cur.handle(), ref.handle(), max_points, max_batch, pnp_max_iterations, &h_));
+  }
+  ~TrackBatch() { sd_track_destroy(h_); }
+  TrackBatch(const TrackBatch&) = delete;
+  TrackBatch& operator=(const TrackBatch&) = delete;
+
+  // Frame statics (src/Frame.cc:158-174)
+  void SetCamera(float fx, float fy, float cx, float cy, float bf, float minX, float maxX, float minY, float maxY) {
+    check(sd_track_set_camera(h_, fx, fy, cx, cy, bf, minX, maxX, minY, maxY));
+  }
+  void SetLastFrame(int frame, const LastFrameView& v) {
+    LastFrameView p = v;   // pad to capacity
+    const int n = v.size();
+    p.valid.resize(max_points_); p.Xw.resize((size_t)max_points_ * 3); p.desc.resize((size_t)max_points_ * 32);
+    p.octave.resize(max_points_); p.angle.resize(max_points_); p.obs.resize(max_points_);
+    check(sd_track_set_last(h_, frame, 1, &n, p.valid.data(), p.Xw.data(), p.desc.data(), p.octave.data(), p.angle.data(),
+                            p.obs.data()));
+  }
+  // LastFrame.GetPose(), CurrentFrame.GetPose() (prior); 16 doubles column-major each
+  void SetPoses(int frame, const double* Tlast, const double* Tcur_prior) { check(sd_track_set_poses(h_, frame, 1, Tlast, Tcur_prior)); }
+  sd_track* handle() { return h_; }
+
+ private:
+  sd_track* h_ = nullptr;
+  int max_points_;
+};
+
+class ImageAlign {
+ public:
+  ImageAlign() {}
+  // bool ComputePose(Frame &CurrentFrame, const Frame &LastFrame) for every pair of the batch;
+  // per-frame results through Result().
+  void ComputePose(TrackBatch& batch, int n_frames, bool keyframe = false, bool fast = false) {
+    check(sd_track_align(batch.handle(), n_frames, keyframe ? (fast ? 2 : 1) : 0));
+  }
+  void ComputePoseKF(TrackBatch& batch, int n_frames) { check(sd_track_align(batch.handle(), n_frames, 3)); }
+  // returns the bool of ComputePose; Tcw = pose set by CurrentFrame.SetPose; error = GetError()
+  bool Result(TrackBatch& batch, int frame, double Tcw[16], double* error = nullptr) {
+    int32_t ok = 0;
+    check(sd_track_get_align(batch.handle(), frame, 1, Tcw, error, &ok, nullptr, nullptr));
+    return ok != 0;
+  }
+};
+
+class ORBmatcher {
+ public:
+  static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;
+  ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+  static int DescriptorDistance(const uint8_t* a, const uint8_t* b) { return sd_hamming(a, b); }
+  // int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+  void SearchByProjection(TrackBatch& batch, int n_frames, float th, bool bMono) {
+    check(sd_track_match(batch.handle(), n_frames, th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0));
+  }
+  // CurrentFrame.mvpMapPoints as indices into LastFrame (-1 = NULL); returns nmatches
+  int Result(TrackBatch& batch, int frame, std::vector<int32_t>& mvpMapPoints, int kp_cap) {
+    mvpMapPoints.resize(kp_cap);
+    int32_t n = 0;
+    check(sd_track_get_matches(batch.handle(), frame, 1, mvpMapPoints.data(), kp_cap, &n));
+    return n;
+  }
+
+ protected:
+  float mfNNratio;
+  bool mbCheckOrientation;
+};
+
+class PnPsolver {
+ public:
+  PnPsolver() { SetRansacParameters(); }
+  void SetRansacParameters(double probability = 0.99, int minInliers = 8, int maxIterations = 300, int minSet = 4, float epsilon = 0.4f,
+                           float th2 = 5.991f) {
+    p_ = probability; minInl_ = minInliers; maxIts_ = maxIterations; minSet_ = minSet; eps_ = epsilon; th2_ = th2;
+  }
+  // cv::Mat iterate(int nIterations, bool &bNoMore, vector<bool> &vbInliers, int &nInliers) for the batch;
+  // rand_values: 4 raw rand() values per iteration and frame (what SD_SLAM::Random would draw)
+  void iterate(TrackBatch& batch, int n_frames, int nIterations, const int32_t* rand_values, int per_frame) {
+    check(sd_track_set_rand(batch.handle(), 0, n_frames, rand_values, per_frame));
+    check(sd_track_pnp(batch.handle(), n_frames, p_, minInl_, maxIts_, minSet_, eps_, th2_, nIterations));
+  }
+  // Tcw: 4x4 CV_32F row-major; returns false for the reference's empty cv::Mat
+  bool Result(TrackBatch& batch, int frame, float Tcw[16], bool& bNoMore, std::vector<uint8_t>& vbInliers, int& nInliers, int kp_cap) {
+    int32_t info[8];
+    vbInliers.resize(kp_cap);
+    check(sd_track_get_pnp(batch.handle(), frame, 1, Tcw, vbInliers.data(), kp_cap, info));
+    bNoMore = info[2] != 0;
+    nInliers = info[1];
+    return info[0] != 0;
+  }
+
+ private:
+  double p_;
+  int minInl_, maxIts_, minSet_;
+  float eps_, th2_;
+};
+
+}  // namespace SD_SLAM

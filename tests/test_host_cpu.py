@@ -137,3 +137,13 @@ def test_hypot_restatement_matches_host_libm_sampled():
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tools", "check_hypot.cc"), "-o", exe, "-lm"])
     out = subprocess.run([exe, "5000000"], capture_output=True, text=True)
     assert out.returncode == 0 and "hypot mismatches 0" in out.stdout, out.stdout
+
+
+def test_cpp_facade_compiles_and_links(sd):
+    exe = "/tmp/sd_facade_check"
+    libdir = os.path.dirname(sd.lib_path())
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "facade_compile.cc"), "-o", exe,
+                           "-L", libdir, "-lsdslam_hip", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "facade ok" in out.stdout, (out.returncode, out.stdout, out.stderr)

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the CPU oracle (the reference ships no golden vectors and
+cannot be built here, so these pin the ORACLE's behaviour against regressions and let the GPU
+tests run against committed data).  Inputs are regenerated from seeds, never stored.
+    python tools/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O          # noqa: E402
+from sdslam_amd import synth            # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+K = (synth.FX, synth.FY, synth.CX, synth.CY)
+BOUNDS = (0.0, 640.0, 0.0, 480.0)
+
+for name, cfg in (("p8", (1000, 1.2, 8, 20)), ("p5", (1000, 2.0, 5, 20))):
+    for seed in (0, 1):
+        e = O.OrbOracle(*cfg)
+        k, d = e.extract(synth.make_image(seed))
+        np.savez_compressed(os.path.join(OUT, f"orb_{name}_seed{seed}.npz"), kps=k, desc=d,
+                            cell_totals=np.concatenate([e.cell_totals(l) for l in range(cfg[2])]),
+                            level_checksum=np.array([int(e.level(l).astype(np.uint64).sum()) for l in range(cfg[2])]))
+
+cfg = (1000, 1.2, 8, 20)
+for seed in (20,):
+    s = synth.make_scene(seed)
+    oc, orf = O.OrbOracle(*cfg), O.OrbOracle(*cfg)
+    ck, cd = oc.extract(s["cur"])
+    rk, rd = orf.extract(s["ref"])
+    last = synth.tracking_case(seed, rk, rd)
+    tab = oc.tables()
+    T0 = synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04)) @ s["T_cur"]
+    al = O.align([oc.level(l) for l in range(8)], [orf.level(l) for l in range(8)], tab["inv_sf"], tab["sf"],
+                 last["Xw"][last["valid"] != 0], s["T_ref"], T0, K, 0)
+    nm, cm = O.search_by_projection(ck, cd, tab["sf"], BOUNDS, K, al["T"], s["T_ref"], last, th=8.0)
+    valid = (cm >= 0).astype(np.uint8)
+    Xw = np.zeros((len(ck), 3))
+    Xw[valid != 0] = last["Xw"][cm[valid != 0]]
+    rs = synth.glibc_rand_stream(800)
+    p = O.PnPOracle(valid, np.stack([ck["x"], ck["y"]], 1), ck["octave"], tab["sigma2"], Xw, K)
+    p.set_ransac(0.99, 10, 200, 4, 0.28, 5.991)
+    r = p.iterate(200, rs)
+    np.savez_compressed(os.path.join(OUT, f"track_seed{seed}.npz"), T0=T0, align_T=al["T"], align_iters=al["iters"],
+                        align_error=al["error"], align_chi2=al["chi2"], n_matches=nm, cur_match=cm,
+                        pnp_T=r["T"], pnp_inliers=r["inliers"], pnp_iterations=r["iterations"], pnp_n_inliers=r["n_inliers"])
+print("golden written to", OUT, sorted(os.listdir(OUT)))
