@@ -137,9 +137,8 @@ __global__ __launch_bounds__(256) void k_pyr_level(const OrbPlan* __restrict__ P
 // The cell (+3 px ring halo) is staged once through LDS in aligned 4-byte words; scores live in
 // a byte map in LDS; ordered emission uses wave ballots over wave-contiguous pixel ranges.
 // ------------------------------------------------------------------------------------------
-template <int SH>
-__device__ __forceinline__ int sh_idx(int k) { return (k + SH) & 15; }
-
+// Full FAST-9/16 decision + score for one pixel whose 7x7 neighbourhood is in LDS.
+// Returns 0 when the pixel is not a corner, else cornerScore<16> (>= threshold).
 __device__ __forceinline__ int fast_score(const uint8_t* __restrict__ c, int tp, int th) {
   // ring offsets (dx,dy), clockwise from (0,3): SURVEY App. A1
   const int v = c[0];
@@ -160,13 +159,13 @@ __device__ __forceinline__ int fast_score(const uint8_t* __restrict__ c, int tp,
   d[13] = v - c[tp - 3];
   d[14] = v - c[2 * tp - 2];
   d[15] = v - c[3 * tp - 1];
-  // quick reject on the 4 compass pairs, then the full 9-contiguous test on bit masks
   unsigned dark = 0, bright = 0;   // dark: p < v - th  <=> d > th ; bright: p > v + th <=> d < -th
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     dark |= (unsigned)(d[k] > th) << k;
     bright |= (unsigned)(d[k] < -th) << k;
   }
+  // >= 9 contiguous set bits on the 16-ring (wrap-around)
   unsigned md = dark | (dark << 16), mb = bright | (bright << 16);
   unsigned rd = md & (md >> 1);
   rd &= rd >> 2;
@@ -200,6 +199,13 @@ __device__ __forceinline__ int fast_score(const uint8_t* __restrict__ c, int tp,
   return max(a, -b) - 1;
 }
 
+// Structure of one strip (a cell is one strip unless it is too large for LDS):
+//   A. every wave owns a contiguous band of rows; per 64-px row segment a 4-read compass test
+//      (a 9-arc always contains two ADJACENT compass points of the same polarity) rejects most
+//      pixels; survivors are appended, in raster order, to the wave's LDS queue (ballot prefix);
+//   B. the queue is processed densely (all lanes busy): full ring classification + score;
+//   C. after a block barrier, NMS on the queued pixels against the LDS score map, then ordered
+//      emission (wave bands are contiguous in raster order, so per-wave counts give offsets).
 __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ P,
                                                     const CellGeom* __restrict__ cells,
                                                     const uint8_t* __restrict__ pyr,
@@ -224,8 +230,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
   const int TPW = (sh + zw + 6 + 3) >> 2;   // tile pitch in 4-byte words
   const int TP = TPW * 4;
   const int SP = (zw + 2 + 3) & ~3;         // score-map pitch (bytes)
+  const int RPW = (S + 2 + 3) >> 2;         // score rows per wave (upper bound)
+  const int QCAP = RPW * zw;                // queue entries per wave (worst case: every pixel)
   uint8_t* tile = smem;
   uint8_t* sc = smem + (size_t)TP * (S + 2 + 6);
+  uint16_t* queue = (uint16_t*)(sc + (size_t)SP * (S + 2 + 2)) + (size_t)wave * QCAP;
+  const unsigned magic = 0xFFFFFFFFu / (unsigned)zw + 1u;   // q / zw == umulhi(q, magic) for q < 2^16, zw < 2^12
+  const unsigned long long lt = lanemask_lt();
   int total = 0;
 
   for (int r0 = 0; r0 < zh; r0 += S) {
@@ -233,47 +244,70 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
     const int sr0 = max(r0 - 1, 0), sr1 = min(r1 + 1, zh);   // zone rows whose scores are needed
     const int nsr = sr1 - sr0;
     const int npr = nsr + 6;
-    // ---- stage pixels: padded rows (zy0 + sr0 - 3 + 19) .. , aligned words
+    // ---- stage pixels (aligned words) and clear the score map
     {
       const uint8_t* g = img + (size_t)(C.zy0 + sr0 - 3 + SD_EDGE) * L.pstride + xa;
-      const int nwords = npr * TPW;
-      for (int i = tid; i < nwords; i += 256) {
-        int row = i / TPW, wc = i - row * TPW;
-        ((uint32_t*)tile)[i] = *(const uint32_t*)(g + (size_t)row * L.pstride + wc * 4);
-      }
+      for (int row = wave; row < npr; row += 4)
+        for (int wc = lane; wc < TPW; wc += 64)
+          ((uint32_t*)tile)[row * TPW + wc] = *(const uint32_t*)(g + (size_t)row * L.pstride + wc * 4);
       const int nsc = ((nsr + 2) * SP) >> 2;
       for (int i = tid; i < nsc; i += 256) ((uint32_t*)sc)[i] = 0;
     }
     __syncthreads();
-    // ---- corner test + score for every zone pixel of the needed rows
-    {
-      const int n = nsr * zw;
-      for (int q = tid; q < n; q += 256) {
-        int y = q / zw, x = q - y * zw;
-        const uint8_t* c = tile + (y + 3) * TP + x + 3 + sh;
-        int s = fast_score(c, TP, th);
+    // ---- A: compass quick test, ordered queue per wave
+    const int rpw = (nsr + 3) >> 2;
+    const int y_lo = min(wave * rpw, nsr), y_hi = min(y_lo + rpw, nsr);
+    int qn = 0;
+    for (int y = y_lo; y < y_hi; y++) {
+      const uint8_t* rowc = tile + (y + 3) * TP + 3 + sh;
+      for (int x0 = 0; x0 < zw; x0 += 64) {
+        const int x = x0 + lane;
+        bool pass = false;
+        if (x < zw) {
+          const uint8_t* c = rowc + x;
+          const int v = c[0];
+          const int d0 = v - c[3 * TP], d4 = v - c[3], d8 = v - c[-3 * TP], d12 = v - c[-3];
+          const unsigned dk = (unsigned)(d0 > th) | ((unsigned)(d4 > th) << 1) | ((unsigned)(d8 > th) << 2) | ((unsigned)(d12 > th) << 3);
+          const unsigned br = (unsigned)(d0 < -th) | ((unsigned)(d4 < -th) << 1) | ((unsigned)(d8 < -th) << 2) | ((unsigned)(d12 < -th) << 3);
+          const unsigned dr = ((dk << 1) | (dk >> 3)) & 15u, brr = ((br << 1) | (br >> 3)) & 15u;
+          pass = ((dk & dr) | (br & brr)) != 0;
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) queue[qn + __popcll(m & lt)] = (uint16_t)(y * zw + x);
+        qn += __popcll(m);
+      }
+    }
+    // ---- B: full test + score on the queued pixels
+    for (int e0 = 0; e0 < qn; e0 += 64) {
+      const int e = e0 + lane;
+      if (e < qn) {
+        const unsigned q = queue[e];
+        const int y = (int)__umulhi(q, magic), x = (int)q - y * zw;
+        const int s = fast_score(tile + (y + 3) * TP + x + 3 + sh, TP, th);
         if (s > 0) sc[(y + 1) * SP + x + 1] = (uint8_t)s;
       }
     }
     __syncthreads();
-    // ---- NMS + ordered emission (wave w owns a contiguous raster range of the strip)
+    // ---- C: NMS + ordered emission
     {
-      const int npx = (r1 - r0) * zw;
-      const int Q = (((npx + 3) >> 2) + 63) & ~63;
-      const int nj = Q >> 6;
       unsigned long long bits = 0;
       int cnt = 0;
+      const int nj = (qn + 63) >> 6;
       for (int j = 0; j < nj; j++) {
-        int q = wave * Q + j * 64 + lane;
+        const int e = j * 64 + lane;
         bool keep = false;
-        if (q < npx) {
-          int ry = q / zw, x = q - ry * zw;
-          const uint8_t* p = sc + (r0 + ry - sr0 + 1) * SP + x + 1;
-          int s = p[0];
-          keep = s > 0 && s > p[-1] && s > p[1] && s > p[-SP - 1] && s > p[-SP] && s > p[-SP + 1] &&
-                 s > p[SP - 1] && s > p[SP] && s > p[SP + 1];
+        if (e < qn) {
+          const unsigned q = queue[e];
+          const int y = (int)__umulhi(q, magic), x = (int)q - y * zw;
+          const int yz = sr0 + y;
+          if (yz >= r0 && yz < r1) {
+            const uint8_t* p = sc + (y + 1) * SP + x + 1;
+            const int s = p[0];
+            keep = s > 0 && s > p[-1] && s > p[1] && s > p[-SP - 1] && s > p[-SP] && s > p[-SP + 1] &&
+                   s > p[SP - 1] && s > p[SP] && s > p[SP + 1];
+          }
         }
-        unsigned long long m = __ballot(keep);
+        const unsigned long long m = __ballot(keep);
         cnt += __popcll(m);
         bits |= (unsigned long long)keep << j;
       }
@@ -282,17 +316,16 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
       int base = total;
       for (int w = 0; w < wave; w++) base += wcnt[w];
       const int strip_total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-      const unsigned long long lt = lanemask_lt();
       for (int j = 0; j < nj; j++) {
-        bool keep = (bits >> j) & 1ull;
-        unsigned long long m = __ballot(keep);
+        const bool keep = (bits >> j) & 1ull;
+        const unsigned long long m = __ballot(keep);
         if (keep) {
-          int q = wave * Q + j * 64 + lane;
-          int ry = q / zw, x = q - ry * zw;
-          int s = sc[(r0 + ry - sr0 + 1) * SP + x + 1];
-          unsigned pos = (unsigned)(base + __popcll(m & lt));
+          const unsigned q = queue[j * 64 + lane];
+          const int y = (int)__umulhi(q, magic), x = (int)q - y * zw;
+          const int s = sc[(y + 1) * SP + x + 1];
+          const unsigned pos = (unsigned)(base + __popcll(m & lt));
           if (pos < C.cap)
-            out[pos] = ((uint32_t)s << 24) | ((uint32_t)(C.zy0 + r0 + ry) << 12) | (uint32_t)(C.zx0 + x);
+            out[pos] = ((uint32_t)s << 24) | ((uint32_t)(C.zy0 + sr0 + y) << 12) | (uint32_t)(C.zx0 + x);
         }
         base += __popcll(m);
       }
@@ -445,48 +478,66 @@ __global__ __launch_bounds__(256) void k_select_level(const OrbPlan* __restrict_
 // k_blur: GaussianBlur(7x7, sigma 2, REFLECT_101) in OpenCV's 8-bit fixed point: integer taps
 // round(g*256) = {18,34,49,55,49,34,18}, row pass in int32, column pass (sum + 2^15) >> 16,
 // saturated.  The padded pyramid already holds the REFLECT_101 border, so no border logic.
-// One 64x16 output tile per workgroup; only levels that own keypoints are blurred
-// (src/ORBextractor.cc:655-660).
+// Register sliding window, no LDS: a thread owns 4 adjacent output columns of a 32-row band,
+// reads each input row as 3 aligned dwords (12 bytes cover the 4+6 taps), keeps the last 7
+// row-pass results in registers and emits one packed 4-byte store per row.  Only levels that
+// own keypoints are blurred (src/ORBextractor.cc:655-660).
 // ------------------------------------------------------------------------------------------
+#define BLUR_RB 32                  // output rows per wave
+#define BLUR_TW 256                 // output columns per workgroup (64 lanes x 4)
+#define BLUR_TH (4 * BLUR_RB)       // output rows per workgroup (4 waves)
+
 __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, const BlurTile* __restrict__ tiles,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                               const int32_t* __restrict__ sel_count) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_in[22][80];
-  __shared__ uint16_t s_h[22][64];
   const BlurTile T = tiles[blockIdx.x];
-  const int frame = blockIdx.y, tid = threadIdx.x;
+  const int frame = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (sel_count[(size_t)frame * P->nlevels + T.level] <= 0) return;
   const LevelGeom L = P->lv[T.level];
+  const int x0 = T.tx * BLUR_TW + lane * 4;
+  const int y0 = T.ty * BLUR_TH + wave * BLUR_RB;
+  if (x0 >= L.w || y0 >= L.h) return;
   const size_t fo = (size_t)frame * P->pyr_frame_bytes + L.off;
-  const uint8_t* src = pyr + fo;
-  // tile origin: interior (tx*64, ty*16) -> padded (tx*64 + 19, ty*16 + 19); taps reach -3..+3
-  const int px0 = T.tx * 64 + SD_EDGE - 3;   // = tx*64 + 16 : 16-byte aligned
-  const int py0 = T.ty * 16 + SD_EDGE - 3;
-  for (int i = tid; i < 22 * 18; i += 256) {   // 18 words = 72 bytes per row
-    int r = i / 18, wc = i - r * 18;
-    int gy = min(py0 + r, L.prows - 1);
-    int gx = px0 + wc * 4;
-    uint32_t v = 0;
-    if (gx + 3 < L.pstride) v = *(const uint32_t*)(src + (size_t)gy * L.pstride + gx);
-    *(uint32_t*)(&s_in[r][wc * 4]) = v;
-  }
-  __syncthreads();
-  for (int i = tid; i < 22 * 64; i += 256) {
-    int r = i >> 6, x = i & 63;
-    const uint8_t* p = &s_in[r][x];
-    int s = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-    s_h[r][x] = (uint16_t)s;   // <= 255*257 = 65535
-  }
-  __syncthreads();
-  uint8_t* dst = blur + fo;
-  for (int i = tid; i < 16 * 64; i += 256) {
-    int y = i >> 6, x = i & 63;
-    int X = T.tx * 64 + x, Y = T.ty * 16 + y;
-    if (X < L.w && Y < L.h) {
-      int s = 18 * ((int)s_h[y][x] + s_h[y + 6][x]) + 34 * ((int)s_h[y + 1][x] + s_h[y + 5][x]) +
-              49 * ((int)s_h[y + 2][x] + s_h[y + 4][x]) + 55 * (int)s_h[y + 3][x];
-      int v = (s + (1 << 15)) >> 16;
-      dst[(size_t)(Y + SD_EDGE) * L.pstride + X + SD_EDGE] = (uint8_t)(v > 255 ? 255 : v);
+  // input bytes for outputs x0..x0+3: padded columns x0+16 .. x0+27 (4-byte aligned)
+  const uint8_t* src = pyr + fo + (size_t)(y0 + SD_EDGE - 3) * L.pstride + (x0 + SD_EDGE - 3);
+  uint8_t* dst = blur + fo + (size_t)(y0 + SD_EDGE) * L.pstride + (x0 + SD_EDGE);
+  const int nrows = min(BLUR_RB, L.h - y0);
+  const bool full = x0 + 3 < L.w;
+  int ring[7][4];
+#pragma unroll
+  for (int r = 0; r < BLUR_RB + 6; r++) {
+    if (r < nrows + 6) {
+      const uint32_t* rp = (const uint32_t*)(src + (size_t)r * L.pstride);
+      const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2];
+      int b[12];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        b[k] = (w0 >> (8 * k)) & 0xff;
+        b[4 + k] = (w1 >> (8 * k)) & 0xff;
+        b[8 + k] = (w2 >> (8 * k)) & 0xff;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        ring[r % 7][k] = 18 * (b[k] + b[k + 6]) + 34 * (b[k + 1] + b[k + 5]) + 49 * (b[k + 2] + b[k + 4]) + 55 * b[k + 3];
+      if (r >= 6) {
+        // output row r-6 uses row-pass results of input rows r-6 .. r (ring slots (r-6+i) % 7)
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int s = 18 * (ring[(r - 6) % 7][k] + ring[r % 7][k]) + 34 * (ring[(r - 5) % 7][k] + ring[(r - 1) % 7][k]) +
+                  49 * (ring[(r - 4) % 7][k] + ring[(r - 2) % 7][k]) + 55 * ring[(r - 3) % 7][k];
+          int v = (s + (1 << 15)) >> 16;
+          v = v > 255 ? 255 : v;
+          packed |= (uint32_t)v << (8 * k);
+        }
+        uint8_t* o = dst + (size_t)(r - 6) * L.pstride;
+        if (full) {
+          __builtin_memcpy(o, &packed, 4);   // interior starts at padded column 19: 4-byte store, 1-byte aligned
+        } else {
+          for (int k = 0; k < 4; k++)
+            if (x0 + k < L.w) o[k] = (uint8_t)(packed >> (8 * k));
+        }
+      }
     }
   }
 }

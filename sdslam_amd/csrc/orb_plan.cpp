@@ -174,12 +174,16 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
           cand += c.cap;
           c.strip_rows = 0;
           if (ok) {
+            // strip height: <= 64 queue chunks per wave (bits in a u64), <= 2^16 queue indices,
+            // LDS = pixel tile + score map + per-wave u16 queues (worst case one entry per pixel)
             int S = std::min(c.zh, std::max(1, 12288 / c.zw));
             for (;;) {
               size_t tp = up((size_t)c.zw + 6 + 3, 4), sp = up((size_t)c.zw + 2, 4);
-              size_t need = tp * (S + 2 + 6) + sp * (S + 2 + 2) + 64;
-              if (need <= 56 * 1024 || S == 1) { lds_max = std::max(lds_max, need); break; }
-              S = std::max(1, S / 2);
+              size_t rpw = (size_t)(S + 2 + 3) / 4;
+              size_t need = tp * (S + 2 + 6) + sp * (S + 2 + 2) + 2 * 4 * rpw * c.zw + 64;
+              bool fits = need <= 60 * 1024 && rpw * c.zw <= 4096 && (size_t)(S + 2) * c.zw < 65536;
+              if (fits || S == 1) { lds_max = std::max(lds_max, need); break; }
+              S = std::max(1, S - std::max(1, S / 8));
             }
             c.strip_rows = S;
           }
@@ -190,8 +194,8 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
     L.cand_cap = cand - L.cand_off;
     hp.max_cells_per_level = std::max(hp.max_cells_per_level, L.ncells);
 
-    for (int ty = 0; ty < (L.h + 15) / 16; ty++)
-      for (int tx = 0; tx < (L.w + 63) / 64; tx++) hp.blur_tiles.push_back(BlurTile{l, tx, ty});
+    for (int ty = 0; ty < (L.h + 127) / 128; ty++)      // k_blur: 256 x 128 output tiles
+      for (int tx = 0; tx < (L.w + 255) / 256; tx++) hp.blur_tiles.push_back(BlurTile{l, tx, ty});
   }
   P.ncells = (int)hp.cells.size();
   P.nsel = sel;
