@@ -27,9 +27,10 @@ namespace sd {
 #define PNP_WORDS (PNP_MAXN / 64)
 
 // ---- one-sided Jacobi SVD (OpenCV 3.2 JacobiSVDImpl_<double>), n <= 12 --------------------
-__device__ void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int vstep, int m, int n, int n1) {
-  const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
-  double W[12];
+// Split in two: the rotation sweeps (jacobi_sweeps / jacobi_sweeps12_reg) and the common tail
+// (final norms, descending sort, normalisation / zero-singular-value fill-in).
+__device__ void jacobi_sweeps(double* At, int astep, double* W, double* Vt, int vstep, int m, int n) {
+  const double eps = DBL_EPSILON * 10;
   int i, j, k, iter, max_iter = m > 30 ? m : 30;
   double c, s, sd;
   for (i = 0; i < n; i++) {
@@ -81,6 +82,78 @@ __device__ void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int 
       }
     if (!changed) break;
   }
+}
+
+// The 12x12 case (EPnP's M^T M, evaluated per RANSAC hypothesis) with the matrix held in
+// REGISTERS: all (i, j, k) loops are unrolled so every index is a compile-time constant; the
+// operation sequence is exactly jacobi_sweeps' (same sums in the same order), only the storage
+// differs.  The right singular vectors are not needed by any 12x12 caller, so Vt is left as the
+// identity (it only rides along in the tail's row swaps).
+__device__ void jacobi_sweeps12_reg(double* At, double* W, double* Vt) {
+  const double eps = DBL_EPSILON * 10;
+  double a[12][12], w[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    double sd = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      a[i][k] = At[i * 12 + k];
+      sd += a[i][k] * a[i][k];
+    }
+    w[i] = sd;
+  }
+  for (int i = 0; i < 144; i++) Vt[i] = (i % 13 == 0) ? 1.0 : 0.0;
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+#pragma unroll
+      for (int j = i + 1; j < 12; j++) {
+        double p = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) p += a[i][k] * a[j][k];
+        if (!(fabs(p) <= eps * sqrt(w[i] * w[j]))) {
+          p *= 2;
+          double c, s;
+          const double beta = w[i] - w[j], gamma = sdsc::hypot_glibc(p, beta);
+          if (beta < 0) {
+            const double delta = (gamma - beta) * 0.5;
+            s = sqrt(delta / gamma);
+            c = p / (gamma * s * 2);
+          } else {
+            c = sqrt((gamma + beta) / (gamma * 2));
+            s = p / (gamma * c * 2);
+          }
+          double na = 0, nb = 0;
+#pragma unroll
+          for (int k = 0; k < 12; k++) {
+            const double t0 = c * a[i][k] + s * a[j][k];
+            const double t1 = -s * a[i][k] + c * a[j][k];
+            a[i][k] = t0;
+            a[j][k] = t1;
+            na += t0 * t0;
+            nb += t1 * t1;
+          }
+          w[i] = na;
+          w[j] = nb;
+          changed = true;
+        }
+      }
+    }
+    if (!changed) break;
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    W[i] = w[i];
+#pragma unroll
+    for (int k = 0; k < 12; k++) At[i * 12 + k] = a[i][k];
+  }
+}
+
+__device__ void jacobi_finish(double* At, int astep, double* W, double* Wout, double* Vt, int vstep, int m, int n, int n1) {
+  const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+  int i, j, k, iter;
+  double s, sd;
   for (i = 0; i < n; i++) {
     for (k = 0, sd = 0; k < m; k++) {
       double t = At[i * astep + k];
@@ -133,6 +206,13 @@ __device__ void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int 
     s = sd > minval ? 1 / sd : 0.;
     for (k = 0; k < m; k++) At[i * astep + k] *= s;
   }
+}
+
+__device__ void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int vstep, int m, int n, int n1) {
+  double W[12];
+  if (m == 12 && n == 12 && astep == 12 && vstep == 12) jacobi_sweeps12_reg(At, W, Vt);
+  else jacobi_sweeps(At, astep, W, Vt, vstep, m, n);
+  jacobi_finish(At, astep, W, Wout, Vt, vstep, m, n, n1);
 }
 
 // SVD of a square row-major n x n matrix (n = 3 or 12): Ut rows = left vectors, Vt rows = right
@@ -255,8 +335,15 @@ __device__ void qr_solve64(double* pA, double* pb, double* pX) {   // 6 x 4 Hous
 struct EpnpCam { double fu, fv, uc, vc; };
 
 // EPnP on n correspondences held in pws (3n) / us (2n); alphas (4n), pcs (3n) are work arrays.
+// WAVE = false: every lane solves its own problem (RANSAC minimal sets).
+// WAVE = true : all 64 lanes of the wave call with IDENTICAL arguments (the refit over the best
+//               inlier set): the sequential parts run redundantly (same cost as one lane), the
+//               M^T M accumulation -- the only O(n * 144) part -- is spread over the lanes, one or
+//               two of the 78 upper-triangle entries per lane, each summed over the correspondences
+//               in the reference's order (bit-identical sums), and exchanged through `lds_mtm`.
+template <bool WAVE>
 __device__ double epnp_compute_pose(int n, const double* pws, const double* us, double* alphas, double* pcs,
-                                    const EpnpCam cam, double R[3][3], double t[3]) {
+                                    const EpnpCam cam, double R[3][3], double t[3], double* lds_mtm = nullptr) {
   double cws[4][3], ccs[4][3];
   // choose_control_points
   cws[0][0] = cws[0][1] = cws[0][2] = 0;
@@ -295,27 +382,53 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
   }
   // M^T M accumulated row by row (rows 2i, 2i+1 of M; same k-order as cvMulTransposed)
   double mtm[144], ut[144], vt[144], d[12];
-  for (int i = 0; i < 144; i++) mtm[i] = 0;
-  for (int i = 0; i < n; i++) {
-    const double* as = alphas + 4 * i;
-    const double u = us[2 * i], v = us[2 * i + 1];
-    double M1[12], M2[12];
-    for (int k = 0; k < 4; k++) {
-      M1[3 * k] = as[k] * cam.fu;
-      M1[3 * k + 1] = 0.0;
-      M1[3 * k + 2] = as[k] * (cam.uc - u);
-      M2[3 * k] = 0.0;
-      M2[3 * k + 1] = as[k] * cam.fv;
-      M2[3 * k + 2] = as[k] * (cam.vc - v);
+  if (WAVE) {
+    const int lane = threadIdx.x & 63;
+    __syncthreads();   // alphas[] (written redundantly by every lane) visible; lds_mtm free
+    for (int e = lane; e < 78; e += 64) {
+      int a = 0, rem = e;
+      while (rem >= 12 - a) { rem -= 12 - a; a++; }
+      const int b = a + rem;
+      const int ka = a / 3, ca = a - 3 * ka, kb = b / 3, cb = b - 3 * kb;
+      double acc = 0;
+      for (int i = 0; i < n; i++) {
+        const double aa = alphas[4 * i + ka], ab = alphas[4 * i + kb];
+        const double u = us[2 * i], v = us[2 * i + 1];
+        const double m1a = ca == 0 ? aa * cam.fu : (ca == 1 ? 0.0 : aa * (cam.uc - u));
+        const double m1b = cb == 0 ? ab * cam.fu : (cb == 1 ? 0.0 : ab * (cam.uc - u));
+        const double m2a = ca == 0 ? 0.0 : (ca == 1 ? aa * cam.fv : aa * (cam.vc - v));
+        const double m2b = cb == 0 ? 0.0 : (cb == 1 ? ab * cam.fv : ab * (cam.vc - v));
+        acc += m1a * m1b;
+        acc += m2a * m2b;
+      }
+      lds_mtm[a * 12 + b] = acc;
+      lds_mtm[b * 12 + a] = acc;
+    }
+    __syncthreads();
+    for (int i = 0; i < 144; i++) mtm[i] = lds_mtm[i];
+  } else {
+    for (int i = 0; i < 144; i++) mtm[i] = 0;
+    for (int i = 0; i < n; i++) {
+      const double* as = alphas + 4 * i;
+      const double u = us[2 * i], v = us[2 * i + 1];
+      double M1[12], M2[12];
+      for (int k = 0; k < 4; k++) {
+        M1[3 * k] = as[k] * cam.fu;
+        M1[3 * k + 1] = 0.0;
+        M1[3 * k + 2] = as[k] * (cam.uc - u);
+        M2[3 * k] = 0.0;
+        M2[3 * k + 1] = as[k] * cam.fv;
+        M2[3 * k + 2] = as[k] * (cam.vc - v);
+      }
+      for (int a = 0; a < 12; a++)
+        for (int b = a; b < 12; b++) {
+          mtm[a * 12 + b] += M1[a] * M1[b];
+          mtm[a * 12 + b] += M2[a] * M2[b];
+        }
     }
     for (int a = 0; a < 12; a++)
-      for (int b = a; b < 12; b++) {
-        mtm[a * 12 + b] += M1[a] * M1[b];
-        mtm[a * 12 + b] += M2[a] * M2[b];
-      }
+      for (int b = 0; b < a; b++) mtm[a * 12 + b] = mtm[b * 12 + a];
   }
-  for (int a = 0; a < 12; a++)
-    for (int b = 0; b < a; b++) mtm[a * 12 + b] = mtm[b * 12 + a];
   svd_square(mtm, 12, d, ut, vt);
   // compute_L_6x10 / compute_rho
   double L[60], rho[6];
@@ -540,6 +653,7 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
   __shared__ unsigned long long s_best[PNP_WORDS], s_ref[PNP_WORDS];
   __shared__ int s_cnt[64];
   __shared__ double s_RtRef[12];
+  __shared__ double s_mtm[144];
   const int f = blockIdx.x, lane = threadIdx.x;
   const int cap = tb.kp_cap;
   const sd_keypoint* kps = kps_all + (size_t)f * cap;
@@ -636,7 +750,7 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
         us[2 * k + 1] = s_p2[val * 2 + 1];
       }
       double R[3][3], t[3];
-      epnp_compute_pose(4, pws, us, alphas, pcs, cam, R, t);
+      epnp_compute_pose<false>(4, pws, us, alphas, pcs, cam, R, t);
       for (int i = 0; i < 9; i++) s_Rt[lane][i] = R[i / 3][i % 3];
       for (int i = 0; i < 3; i++) s_Rt[lane][9 + i] = t[i];
     }
@@ -664,12 +778,12 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
         for (int w = lane; w < nwords; w += 64) s_best[w] = s_mask[h][w];
         for (int i = 0; i < 12; i++) bestT[i] = (float)s_Rt[h][i];
         __syncthreads();
-        // Refine(): EPnP on the best inlier set, then CheckInliers
+        // Refine(): EPnP on the best inlier set (wave-cooperative), then CheckInliers
+        double* pws = scratch;
+        double* us = scratch + 3 * (size_t)cap;
+        double* alphas = scratch + 5 * (size_t)cap;
+        double* pcs = scratch + 9 * (size_t)cap;
         if (lane == 0) {
-          double* pws = scratch;
-          double* us = scratch + 3 * (size_t)cap;
-          double* alphas = scratch + 5 * (size_t)cap;
-          double* pcs = scratch + 9 * (size_t)cap;
           int n = 0;
           for (int i = 0; i < N; i++)
             if ((s_best[i >> 6] >> (i & 63)) & 1ull) {
@@ -680,10 +794,15 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
               us[2 * n + 1] = s_p2[i * 2 + 1];
               n++;
             }
+        }
+        __syncthreads();
+        {
           double R[3][3], t[3];
-          epnp_compute_pose(n, pws, us, alphas, pcs, cam, R, t);
-          for (int i = 0; i < 9; i++) s_RtRef[i] = R[i / 3][i % 3];
-          for (int i = 0; i < 3; i++) s_RtRef[9 + i] = t[i];
+          epnp_compute_pose<true>(best, pws, us, alphas, pcs, cam, R, t, s_mtm);   // best == popcount(s_best)
+          if (lane == 0) {
+            for (int i = 0; i < 9; i++) s_RtRef[i] = R[i / 3][i % 3];
+            for (int i = 0; i < 3; i++) s_RtRef[9 + i] = t[i];
+          }
         }
         __syncthreads();
         int rcnt = 0;
@@ -741,7 +860,7 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
 __global__ void k_epnp_debug(int n, const double* pws, const double* us, double* work, EpnpCam cam, double* out13) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double R[3][3], t[3];
-  double e = epnp_compute_pose(n, pws, us, work, work + 4 * (size_t)n, cam, R, t);
+  double e = epnp_compute_pose<false>(n, pws, us, work, work + 4 * (size_t)n, cam, R, t);
   for (int i = 0; i < 9; i++) out13[i] = R[i / 3][i % 3];
   for (int i = 0; i < 3; i++) out13[9 + i] = t[i];
   out13[12] = e;
