@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic scenes (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--orb-only", action="store_true", help="time ORB extraction alone (configs[1] without tracking)")

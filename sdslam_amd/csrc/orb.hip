@@ -57,6 +57,12 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 //           a border pixel equals the resize result of its reflected interior pixel.
 // Each thread produces 4 horizontally adjacent bytes (one u32 store, coalesced).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);   // global memory runs in unaligned-access mode: one dword load
+  return v;
+}
+
 __global__ __launch_bounds__(256) void k_pyr_level(const OrbPlan* __restrict__ P, int level,
                                                    const uint8_t* __restrict__ src0, int src_stride,
                                                    size_t src_frame_stride, uint8_t* __restrict__ pyr,
@@ -68,15 +74,22 @@ __global__ __launch_bounds__(256) void k_pyr_level(const OrbPlan* __restrict__ P
   if (px >= L.pstride || py >= L.prows) return;
   uint8_t* dstbase = pyr + (size_t)frame * P->pyr_frame_bytes + L.off;
   const int Y = reflect101(py - SD_EDGE, L.h);
+  // fast path: the 4 outputs are interior pixels X0..X0+3 (no reflection, consecutive sources)
+  const int X0 = px - SD_EDGE;
+  const bool interior = X0 >= 0 && X0 + 3 < L.w;
   uint32_t packed = 0;
   if (level == 0) {
     const uint8_t* s = src0 + (size_t)frame * src_frame_stride + (size_t)Y * src_stride;
+    if (interior) {
+      packed = ld_u32_unaligned(s + X0);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int x = px + k;
-      uint32_t v = 0;
-      if (x < L.w + 2 * SD_EDGE) v = s[reflect101(x - SD_EDGE, L.w)];
-      packed |= v << (8 * k);
+      for (int k = 0; k < 4; k++) {
+        int x = px + k;
+        uint32_t v = 0;
+        if (x < L.w + 2 * SD_EDGE) v = s[reflect101(x - SD_EDGE, L.w)];
+        packed |= v << (8 * k);
+      }
     }
   } else {
     const LevelGeom S = P->lv[level - 1];
@@ -84,15 +97,27 @@ __global__ __launch_bounds__(256) void k_pyr_level(const OrbPlan* __restrict__ P
     if (L.area2x2) {
       const uint8_t* r0 = sb + (size_t)(2 * Y) * S.pstride;
       const uint8_t* r1 = r0 + S.pstride;
+      if (interior) {
+        const uint32_t a0 = ld_u32_unaligned(r0 + 2 * X0), a1 = ld_u32_unaligned(r0 + 2 * X0 + 4);
+        const uint32_t b0 = ld_u32_unaligned(r1 + 2 * X0), b1 = ld_u32_unaligned(r1 + 2 * X0 + 4);
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        int x = px + k;
-        uint32_t v = 0;
-        if (x < L.w + 2 * SD_EDGE) {
-          int X = reflect101(x - SD_EDGE, L.w);
-          v = (r0[2 * X] + r0[2 * X + 1] + r1[2 * X] + r1[2 * X + 1] + 2) >> 2;
+        for (int k = 0; k < 4; k++) {
+          const uint32_t ta = k < 2 ? (a0 >> (16 * k)) : (a1 >> (16 * (k - 2)));
+          const uint32_t tb = k < 2 ? (b0 >> (16 * k)) : (b1 >> (16 * (k - 2)));
+          const uint32_t v = ((ta & 0xff) + ((ta >> 8) & 0xff) + (tb & 0xff) + ((tb >> 8) & 0xff) + 2) >> 2;
+          packed |= v << (8 * k);
         }
-        packed |= v << (8 * k);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int x = px + k;
+          uint32_t v = 0;
+          if (x < L.w + 2 * SD_EDGE) {
+            int X = reflect101(x - SD_EDGE, L.w);
+            v = (r0[2 * X] + r0[2 * X + 1] + r1[2 * X] + r1[2 * X + 1] + 2) >> 2;
+          }
+          packed |= v << (8 * k);
+        }
       }
     } else {
       const int32_t* xo = coef + L.cx;
@@ -106,22 +131,60 @@ __global__ __launch_bounds__(256) void k_pyr_level(const OrbPlan* __restrict__ P
       const int b0 = (int)(short)(bb & 0xffff), b1 = (int)(short)((unsigned)bb >> 16);
       const uint8_t* r0 = sb + (size_t)sy0 * S.pstride;
       const uint8_t* r1 = sb + (size_t)sy1 * S.pstride;
+      bool done = false;
+      if (interior) {
+        // the sources of 4 consecutive outputs span <= 12 bytes for scale factors up to 2:
+        // fetch each source row as three dwords and pick bytes out of the registers
+        int sx[4], al[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        int x = px + k;
-        uint32_t v = 0;
-        if (x < L.w + 2 * SD_EDGE) {
-          int X = reflect101(x - SD_EDGE, L.w);
-          int sx = xo[X];
-          int sx1 = sx + 1 < S.w ? sx + 1 : S.w - 1;
-          int aa = xa[X];
-          int a0 = (int)(short)(aa & 0xffff), a1 = (int)(short)((unsigned)aa >> 16);
-          int h0 = r0[sx] * a0 + r0[sx1] * a1;
-          int h1 = r1[sx] * a0 + r1[sx1] * a1;
-          int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-          v = (uint32_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+        for (int k = 0; k < 4; k++) {
+          sx[k] = xo[X0 + k];
+          al[k] = xa[X0 + k];
         }
-        packed |= v << (8 * k);
+        const int base = sx[0];
+        if (sx[3] + 1 - base <= 11 && base + 11 < S.w + SD_EDGE) {   // window stays inside the padded row
+          uint32_t w0[3], w1[3];
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            w0[j] = ld_u32_unaligned(r0 + base + 4 * j);
+            w1[j] = ld_u32_unaligned(r1 + base + 4 * j);
+          }
+          const unsigned long long lo0 = w0[0] | ((unsigned long long)w0[1] << 32), lo1 = w1[0] | ((unsigned long long)w1[1] << 32);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int o = sx[k] - base;            // 0..10
+            const int o1 = (sx[k] + 1 < S.w ? sx[k] + 1 : S.w - 1) - base;
+            const int p00 = o < 8 ? (int)((lo0 >> (8 * o)) & 0xff) : (int)((w0[2] >> (8 * (o - 8))) & 0xff);
+            const int p01 = o1 < 8 ? (int)((lo0 >> (8 * o1)) & 0xff) : (int)((w0[2] >> (8 * (o1 - 8))) & 0xff);
+            const int p10 = o < 8 ? (int)((lo1 >> (8 * o)) & 0xff) : (int)((w1[2] >> (8 * (o - 8))) & 0xff);
+            const int p11 = o1 < 8 ? (int)((lo1 >> (8 * o1)) & 0xff) : (int)((w1[2] >> (8 * (o1 - 8))) & 0xff);
+            const int a0 = (int)(short)(al[k] & 0xffff), a1 = (int)(short)((unsigned)al[k] >> 16);
+            const int h0 = p00 * a0 + p01 * a1;
+            const int h1 = p10 * a0 + p11 * a1;
+            const int ov = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(ov < 0 ? 0 : (ov > 255 ? 255 : ov)) << (8 * k);
+          }
+          done = true;
+        }
+      }
+      if (!done) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int x = px + k;
+          uint32_t v = 0;
+          if (x < L.w + 2 * SD_EDGE) {
+            int X = reflect101(x - SD_EDGE, L.w);
+            int sx = xo[X];
+            int sx1 = sx + 1 < S.w ? sx + 1 : S.w - 1;
+            int aa = xa[X];
+            int a0 = (int)(short)(aa & 0xffff), a1 = (int)(short)((unsigned)aa >> 16);
+            int h0 = r0[sx] * a0 + r0[sx1] * a1;
+            int h1 = r1[sx] * a0 + r1[sx1] * a1;
+            int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = (uint32_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+          }
+          packed |= v << (8 * k);
+        }
       }
     }
   }

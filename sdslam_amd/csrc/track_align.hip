@@ -40,61 +40,66 @@ __device__ __forceinline__ void m4_mul(const double* a, const double* b, double*
 }
 
 // Eigen 3.3 LDLT<Matrix6d>::solve (pivoting on the largest |diagonal|, pseudo-inverse of D)
-__device__ void ldlt_solve6(double A[6][6], const double* b, double* x) {
+// A is a row-major 6x6 in LDS (single lane): private arrays with run-time indices would live in
+// scratch memory, whose latency dominated the serial part of every Gauss-Newton iteration.
+#define A_(r, c) A[(r) * 6 + (c)]
+__device__ void ldlt_solve6(double* A, const double* b, double* x) {
   const int n = 6;
   int tr[6];
   double temp[6];
   for (int k = 0; k < n; ++k) {
     int big = k;
-    double best = fabs(A[k][k]);
+    double best = fabs(A_(k, k));
     for (int i = k + 1; i < n; i++)
-      if (fabs(A[i][i]) > best) { best = fabs(A[i][i]); big = i; }
+      if (fabs(A_(i, i)) > best) { best = fabs(A_(i, i)); big = i; }
     tr[k] = big;
     if (k != big) {
       int s = n - big - 1;
-      for (int j = 0; j < k; j++) { double t = A[k][j]; A[k][j] = A[big][j]; A[big][j] = t; }
-      for (int i = 0; i < s; i++) { double t = A[big + 1 + i][k]; A[big + 1 + i][k] = A[big + 1 + i][big]; A[big + 1 + i][big] = t; }
-      { double t = A[k][k]; A[k][k] = A[big][big]; A[big][big] = t; }
-      for (int i = k + 1; i < big; ++i) { double t = A[i][k]; A[i][k] = A[big][i]; A[big][i] = t; }
+      for (int j = 0; j < k; j++) { double t = A_(k, j); A_(k, j) = A_(big, j); A_(big, j) = t; }
+      for (int i = 0; i < s; i++) { double t = A_(big + 1 + i, k); A_(big + 1 + i, k) = A_(big + 1 + i, big); A_(big + 1 + i, big) = t; }
+      { double t = A_(k, k); A_(k, k) = A_(big, big); A_(big, big) = t; }
+      for (int i = k + 1; i < big; ++i) { double t = A_(i, k); A_(i, k) = A_(big, i); A_(big, i) = t; }
     }
     int rs = n - k - 1;
     if (k > 0) {
-      for (int j = 0; j < k; j++) temp[j] = A[j][j] * A[k][j];
+      for (int j = 0; j < k; j++) temp[j] = A_(j, j) * A_(k, j);
       double s = 0;
-      for (int j = 0; j < k; j++) s += A[k][j] * temp[j];
-      A[k][k] -= s;
+      for (int j = 0; j < k; j++) s += A_(k, j) * temp[j];
+      A_(k, k) -= s;
       for (int i = 0; i < rs; i++) {
         double t = 0;
-        for (int j = 0; j < k; j++) t += A[k + 1 + i][j] * temp[j];
-        A[k + 1 + i][k] -= t;
+        for (int j = 0; j < k; j++) t += A_(k + 1 + i, j) * temp[j];
+        A_(k + 1 + i, k) -= t;
       }
     }
-    double akk = A[k][k];
+    double akk = A_(k, k);
     bool valid = fabs(akk) > 0.0;
     if (k == 0 && !valid) {
       for (int j = 0; j < n; j++) tr[j] = j;
       break;
     }
     if (rs > 0 && valid)
-      for (int i = 0; i < rs; i++) A[k + 1 + i][k] /= akk;
+      for (int i = 0; i < rs; i++) A_(k + 1 + i, k) /= akk;
   }
   double d[6];
   for (int i = 0; i < n; i++) d[i] = b[i];
   for (int k = 0; k < n; k++)
     if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
   for (int i = 0; i < n; i++)
-    for (int j = 0; j < i; j++) d[i] -= A[i][j] * d[j];
+    for (int j = 0; j < i; j++) d[i] -= A_(i, j) * d[j];
   const double tol = 2.2250738585072014e-308;
   for (int i = 0; i < n; i++) {
-    if (fabs(A[i][i]) > tol) d[i] /= A[i][i];
+    if (fabs(A_(i, i)) > tol) d[i] /= A_(i, i);
     else d[i] = 0;
   }
   for (int i = n - 1; i >= 0; i--)
-    for (int j = i + 1; j < n; j++) d[i] -= A[j][i] * d[j];
+    for (int j = i + 1; j < n; j++) d[i] -= A_(j, i) * d[j];
   for (int k = n - 1; k >= 0; k--)
     if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
   for (int i = 0; i < n; i++) x[i] = d[i];
 }
+
+#undef A_
 
 // ImageAlign::Exp (translation-first twist) -> row-major 4x4
 __device__ void se3_exp(const double* update, double* res) {
@@ -154,9 +159,10 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
   __shared__ double s_pts[AL_MAXP * 3];
   __shared__ double s_xyz[AL_MAXP * 3];
   __shared__ uint8_t s_vis[AL_MAXP + 4];
-  __shared__ float s_chi[AL_MAXP * 16];
+  __shared__ __attribute__((aligned(16))) float s_chi[AL_MAXP * 16];
   __shared__ double s_red[4][28];
   __shared__ double s_last[16], s_se3[16], s_pose[16], s_bk[16];
+  __shared__ double s_H[36], s_b[6], s_x[6];
   __shared__ int s_cnt[4];
   __shared__ int s_ctrl[4];   // [0] break flag, [1] npts
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -384,23 +390,33 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
       // ------------------------------------------------ Optimize (serial part)
       if (tid == 0) {
         iters[level] = it + 1;
-        double Hm[6][6], b[6], x[6];
         int q = 0;
         for (int a = 0; a < 6; a++)
           for (int bb = a; bb < 6; bb++) {
             double v = ((s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]));
-            Hm[a][bb] = v;
-            Hm[bb][a] = v;
+            s_H[a * 6 + bb] = v;
+            s_H[bb * 6 + a] = v;
             q++;
           }
-        for (int a = 0; a < 6; a++) b[a] = ((s_red[0][21 + a] + s_red[1][21 + a]) + (s_red[2][21 + a] + s_red[3][21 + a]));
+        for (int a = 0; a < 6; a++) s_b[a] = ((s_red[0][21 + a] + s_red[1][21 + a]) + (s_red[2][21 + a] + s_red[3][21 + a]));
         const int n_meas = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        // float chi2 in the reference's order; 16-byte LDS reads are issued ahead of the dependent adds
         float chi2f = 0.0f;
-        const int npx = npts * 16;
-        for (int i = 0; i < npx; i++) chi2f += s_chi[i];
+        const float4* c4 = (const float4*)s_chi;
+        const int n4 = npts * 4;
+#pragma unroll 8
+        for (int i = 0; i < n4; i++) {
+          const float4 v = c4[i];
+          chi2f += v.x;
+          chi2f += v.y;
+          chi2f += v.z;
+          chi2f += v.w;
+        }
         const double new_chi2 = (double)(chi2f / (float)n_meas);   // float/size_t -> float, then widened
         if (n_meas == 0) stop_ = true;
-        ldlt_solve6(Hm, b, x);
+        ldlt_solve6(s_H, s_b, s_x);
+        double x[6];
+        for (int i = 0; i < 6; i++) x[i] = s_x[i];
         if (isnan(x[0])) stop_ = true;
         int brk = 0;
         if ((it > 0 && new_chi2 > chi2_) || stop_) {

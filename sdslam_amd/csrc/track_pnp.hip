@@ -25,6 +25,7 @@ namespace sd {
 
 #define PNP_MAXN 1024
 #define PNP_WORDS (PNP_MAXN / 64)
+#define PNP_CHUNK 16   // RANSAC hypotheses evaluated side by side (typical runs accept within the first few)
 
 // ---- one-sided Jacobi SVD (OpenCV 3.2 JacobiSVDImpl_<double>), n <= 12 --------------------
 // Split in two: the rotation sweeps (jacobi_sweeps / jacobi_sweeps12_reg) and the common tail
@@ -345,6 +346,10 @@ template <bool WAVE>
 __device__ double epnp_compute_pose(int n, const double* pws, const double* us, double* alphas, double* pcs,
                                     const EpnpCam cam, double R[3][3], double t[3], double* lds_mtm = nullptr) {
   double cws[4][3], ccs[4][3];
+  // In WAVE mode only lane 0 runs the sequential parts (63 idle lanes issue no private-memory
+  // traffic); every lane joins the barriers and the M^T M accumulation.
+  const bool lead = !WAVE || (threadIdx.x & 63) == 0;
+  if (lead) {
   // choose_control_points
   cws[0][0] = cws[0][1] = cws[0][2] = 0;
   for (int i = 0; i < n; i++)
@@ -380,6 +385,7 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
       a[0] = 1.0f - a[1] - a[2] - a[3];
     }
   }
+  }  // lead
   // M^T M accumulated row by row (rows 2i, 2i+1 of M; same k-order as cvMulTransposed)
   double mtm[144], ut[144], vt[144], d[12];
   if (WAVE) {
@@ -405,7 +411,8 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
       lds_mtm[b * 12 + a] = acc;
     }
     __syncthreads();
-    for (int i = 0; i < 144; i++) mtm[i] = lds_mtm[i];
+    if (lead)
+      for (int i = 0; i < 144; i++) mtm[i] = lds_mtm[i];
   } else {
     for (int i = 0; i < 144; i++) mtm[i] = 0;
     for (int i = 0; i < n; i++) {
@@ -429,6 +436,8 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
     for (int a = 0; a < 12; a++)
       for (int b = 0; b < a; b++) mtm[a * 12 + b] = mtm[b * 12 + a];
   }
+  double bestR[3][3], bestT[3], best_err = 0;
+  if (lead) {
   svd_square(mtm, 12, d, ut, vt);
   // compute_L_6x10 / compute_rho
   double L[60], rho[6];
@@ -468,7 +477,6 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
     rho[4] = dist2_3(cws[1], cws[3]);
     rho[5] = dist2_3(cws[2], cws[3]);
   }
-  double bestR[3][3], bestT[3], best_err = 0;
   for (int variant = 1; variant <= 3; variant++) {
     double betas[4];
     if (variant == 1) {
@@ -626,6 +634,7 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
     for (int j = 0; j < 3; j++) R[i][j] = bestR[i][j];
     t[i] = bestT[i];
   }
+  }  // lead
   return best_err;
 }
 
@@ -722,10 +731,10 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
   for (int i = 0; i < 12; i++) bestT[i] = 0.f;
   double* scratch = tb.pnp_scratch + (size_t)f * cap * 12;
 
-  for (int c0 = 0; c0 < total; c0 += 64) {
+  for (int c0 = 0; c0 < total; c0 += PNP_CHUNK) {
     const int it = c0 + lane;
-    const int nact = min(64, total - c0);
-    if (it < total) {
+    const int nact = min(PNP_CHUNK, total - c0);
+    if (lane < nact) {
       // minimal set: 4 draws without replacement from mvAllIndices via swap-with-back removal
       int modp[4], modv[4], nmod = 0, size = N;
       double pws[12], us[8], alphas[16], pcs[12];
