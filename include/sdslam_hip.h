@@ -169,6 +169,7 @@ int sd_track_get_pnp(sd_track* h, int frame0, int n_frames, float* Tcw_rowmajor,
  * correspondences; R9 row-major, returns the mean reprojection error in *reproj_err */
 int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy,
                   double* R9, double* t3, double* reproj_err);
+int sd_track_debug_read(sd_track* h, int which, int frame, void* out, size_t bytes);
 int sd_track_set_profiling(sd_track* h, int on);
 int sd_track_stage_ms(sd_track* h, float* ms_out /* [0]=align, [1]=match, [2]=pnp */, int cap);
 

@@ -96,6 +96,8 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.pnp_inliers, B * K));
   A(dalloc(h, &tb.pnp_info, B * 8));
   A(dalloc(h, &tb.pnp_scratch, B * K * 12));
+  A(dalloc(h, &tb.pnp_pts, B * K * 6));
+  A(dalloc(h, &tb.pnp_kpidx, B * K));
   A(dalloc(h, &h->d_sf, (size_t)cur->nlevels));
   A(dalloc(h, &h->d_inv_sf, (size_t)cur->nlevels));
   A(dalloc(h, &h->d_sigma2, (size_t)cur->nlevels));
@@ -290,6 +292,17 @@ int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double f
                   double* reproj_err) {
   SD_REQUIRE(n >= 4 && Xw && uv && R9 && t3, SD_ERR_INVALID_ARG, "bad arguments");
   return run_epnp_debug(n, Xw, uv, fx, fy, cx, cy, R9, t3, reproj_err);
+}
+
+// diagnostics: raw copy of an internal per-frame buffer (0: pnp correspondences f32[kp_cap*6], 1: pnp keypoint indices u16[kp_cap])
+int sd_track_debug_read(sd_track* h, int which, int frame, void* out, size_t bytes) {
+  SD_REQUIRE(h && out && frame >= 0 && frame < h->max_batch, SD_ERR_INVALID_ARG, "bad arguments");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipStreamSynchronize(h->cur->stream));
+  const void* src = which == 0 ? (const void*)(h->tb.pnp_pts + (size_t)frame * h->kp_cap * 6)
+                               : (const void*)(h->tb.pnp_kpidx + (size_t)frame * h->kp_cap);
+  SD_HIP_CHECK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+  return SD_OK;
 }
 
 int sd_track_set_profiling(sd_track* h, int on) {

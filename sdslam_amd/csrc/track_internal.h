@@ -37,6 +37,8 @@ struct TrackBuffers {
   uint8_t* pnp_inliers;  // [B][kp_cap]
   int32_t* pnp_info;     // [B][8]: ok, nInliers, noMore, iterations, N, minInliers, maxIts, refined
   double* pnp_scratch;   // [B][kp_cap*12] EPnP per-correspondence work arrays (pws, us, alphas, pcs)
+  float* pnp_pts;        // [B][kp_cap][6] gathered correspondences {u, v, X, Y, Z, maxErr}
+  uint16_t* pnp_kpidx;   // [B][kp_cap] mvKeyPointIndices
 };
 
 struct TrackCam {

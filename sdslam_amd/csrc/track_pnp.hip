@@ -24,8 +24,18 @@
 namespace sd {
 
 #define PNP_MAXN 1024
-#define PNP_WORDS (PNP_MAXN / 64)
 #define PNP_CHUNK 16   // RANSAC hypotheses evaluated side by side (typical runs accept within the first few)
+#define PNP_WORDS (PNP_MAXN / 64)
+
+// Lane-interleaved LDS array: element i of this lane lives at p[i * PNP_CHUNK], so the
+// PNP_CHUNK lanes that solve hypotheses side by side hit distinct banks.  The big per-lane EPnP
+// work arrays (12x12 Gram / singular-vector matrix, L_6x10) live here instead of in private
+// (scratch) memory: with 9 KB of scratch per lane the kernel was bound by scratch traffic.
+struct LArr {
+  double* p;
+  __device__ __forceinline__ double& operator[](int i) const { return p[i * PNP_CHUNK]; }
+  __device__ __forceinline__ LArr operator+(int off) const { return LArr{p + off * PNP_CHUNK}; }
+};
 
 // ---- one-sided Jacobi SVD (OpenCV 3.2 JacobiSVDImpl_<double>), n <= 12 --------------------
 // Split in two: the rotation sweeps (jacobi_sweeps / jacobi_sweeps12_reg) and the common tail
@@ -90,7 +100,8 @@ __device__ void jacobi_sweeps(double* At, int astep, double* W, double* Vt, int 
 // operation sequence is exactly jacobi_sweeps' (same sums in the same order), only the storage
 // differs.  The right singular vectors are not needed by any 12x12 caller, so Vt is left as the
 // identity (it only rides along in the tail's row swaps).
-__device__ void jacobi_sweeps12_reg(double* At, double* W, double* Vt) {
+template <typename Ptr>
+__device__ void jacobi_sweeps12_reg(Ptr At, double* W) {
   const double eps = DBL_EPSILON * 10;
   double a[12][12], w[12];
 #pragma unroll
@@ -103,7 +114,6 @@ __device__ void jacobi_sweeps12_reg(double* At, double* W, double* Vt) {
     }
     w[i] = sd;
   }
-  for (int i = 0; i < 144; i++) Vt[i] = (i % 13 == 0) ? 1.0 : 0.0;
   for (int iter = 0; iter < 30; iter++) {
     bool changed = false;
 #pragma unroll
@@ -151,7 +161,8 @@ __device__ void jacobi_sweeps12_reg(double* At, double* W, double* Vt) {
   }
 }
 
-__device__ void jacobi_finish(double* At, int astep, double* W, double* Wout, double* Vt, int vstep, int m, int n, int n1) {
+template <typename Ptr>
+__device__ void jacobi_finish(Ptr At, int astep, double* W, double* Wout, double* Vt, int vstep, int m, int n, int n1) {
   const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
   int i, j, k, iter;
   double s, sd;
@@ -169,7 +180,8 @@ __device__ void jacobi_finish(double* At, int astep, double* W, double* Wout, do
     if (i != j) {
       double tw = W[i]; W[i] = W[j]; W[j] = tw;
       for (k = 0; k < m; k++) { double t = At[i * astep + k]; At[i * astep + k] = At[j * astep + k]; At[j * astep + k] = t; }
-      for (k = 0; k < n; k++) { double t = Vt[i * vstep + k]; Vt[i * vstep + k] = Vt[j * vstep + k]; Vt[j * vstep + k] = t; }
+      if (Vt)
+        for (k = 0; k < n; k++) { double t = Vt[i * vstep + k]; Vt[i * vstep + k] = Vt[j * vstep + k]; Vt[j * vstep + k] = t; }
     }
   }
   for (i = 0; i < n; i++) Wout[i] = W[i];
@@ -211,9 +223,19 @@ __device__ void jacobi_finish(double* At, int astep, double* W, double* Wout, do
 
 __device__ void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int vstep, int m, int n, int n1) {
   double W[12];
-  if (m == 12 && n == 12 && astep == 12 && vstep == 12) jacobi_sweeps12_reg(At, W, Vt);
-  else jacobi_sweeps(At, astep, W, Vt, vstep, m, n);
+  jacobi_sweeps(At, astep, W, Vt, vstep, m, n);
   jacobi_finish(At, astep, W, Wout, Vt, vstep, m, n, n1);
+}
+
+// cvSVD of the symmetric 12x12 M^T M held (in place) in `A`: on return rows of A are the left
+// singular vectors (descending singular values).  A^T == A, so no transpose copy is needed; the
+// right singular vectors are not needed by EPnP and are not formed (they only ride along in
+// JacobiSVDImpl_'s final row swaps).
+template <typename Ptr>
+__device__ void svd_sym12_inplace(Ptr A, double* Wout) {
+  double W[12];
+  jacobi_sweeps12_reg(A, W);
+  jacobi_finish(A, 12, W, Wout, (double*)nullptr, 12, 12, 12, 12);
 }
 
 // SVD of a square row-major n x n matrix (n = 3 or 12): Ut rows = left vectors, Vt rows = right
@@ -342,9 +364,10 @@ struct EpnpCam { double fu, fv, uc, vc; };
 //               M^T M accumulation -- the only O(n * 144) part -- is spread over the lanes, one or
 //               two of the 78 upper-triangle entries per lane, each summed over the correspondences
 //               in the reference's order (bit-identical sums), and exchanged through `lds_mtm`.
-template <bool WAVE>
+template <bool WAVE, typename Ptr>
 __device__ double epnp_compute_pose(int n, const double* pws, const double* us, double* alphas, double* pcs,
-                                    const EpnpCam cam, double R[3][3], double t[3], double* lds_mtm = nullptr) {
+                                    const EpnpCam cam, double R[3][3], double t[3], Ptr ut /* 144 */, Ptr L /* 60 */,
+                                    double* lds_mtm = nullptr) {
   double cws[4][3], ccs[4][3];
   // In WAVE mode only lane 0 runs the sequential parts (63 idle lanes issue no private-memory
   // traffic); every lane joins the barriers and the M^T M accumulation.
@@ -386,11 +409,12 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
     }
   }
   }  // lead
-  // M^T M accumulated row by row (rows 2i, 2i+1 of M; same k-order as cvMulTransposed)
-  double mtm[144], ut[144], vt[144], d[12];
+  // M^T M accumulated row by row (rows 2i, 2i+1 of M; same k-order as cvMulTransposed), built
+  // in place in `ut` (it is symmetric, so it equals the transposed copy cvSVD would make)
+  double d[12];
   if (WAVE) {
     const int lane = threadIdx.x & 63;
-    __syncthreads();   // alphas[] (written redundantly by every lane) visible; lds_mtm free
+    __syncthreads();   // alphas[] (written by the lead lane) visible; lds_mtm free
     for (int e = lane; e < 78; e += 64) {
       int a = 0, rem = e;
       while (rem >= 12 - a) { rem -= 12 - a; a++; }
@@ -412,9 +436,9 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
     }
     __syncthreads();
     if (lead)
-      for (int i = 0; i < 144; i++) mtm[i] = lds_mtm[i];
+      for (int i = 0; i < 144; i++) ut[i] = lds_mtm[i];
   } else {
-    for (int i = 0; i < 144; i++) mtm[i] = 0;
+    for (int i = 0; i < 144; i++) ut[i] = 0;
     for (int i = 0; i < n; i++) {
       const double* as = alphas + 4 * i;
       const double u = us[2 * i], v = us[2 * i + 1];
@@ -429,20 +453,22 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
       }
       for (int a = 0; a < 12; a++)
         for (int b = a; b < 12; b++) {
-          mtm[a * 12 + b] += M1[a] * M1[b];
-          mtm[a * 12 + b] += M2[a] * M2[b];
+          double acc = ut[a * 12 + b];
+          acc += M1[a] * M1[b];
+          acc += M2[a] * M2[b];
+          ut[a * 12 + b] = acc;
         }
     }
     for (int a = 0; a < 12; a++)
-      for (int b = 0; b < a; b++) mtm[a * 12 + b] = mtm[b * 12 + a];
+      for (int b = 0; b < a; b++) ut[a * 12 + b] = ut[b * 12 + a];
   }
   double bestR[3][3], bestT[3], best_err = 0;
   if (lead) {
-  svd_square(mtm, 12, d, ut, vt);
+  svd_sym12_inplace(ut, d);
   // compute_L_6x10 / compute_rho
-  double L[60], rho[6];
+  double rho[6];
   {
-    const double* v4[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
+    const Ptr v4[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
     double dv[4][6][3];
     for (int i = 0; i < 4; i++) {
       int a = 0, b = 1;
@@ -458,7 +484,7 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
       }
     }
     for (int i = 0; i < 6; i++) {
-      double* row = L + 10 * i;
+      Ptr row = L + 10 * i;
       row[0] = dot3(dv[0][i], dv[0][i]);
       row[1] = 2.0f * dot3(dv[0][i], dv[1][i]);
       row[2] = dot3(dv[1][i], dv[1][i]);
@@ -537,7 +563,7 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
     for (int k = 0; k < 5; k++) {
       double a[24], b[6], x[4] = {0, 0, 0, 0};
       for (int i = 0; i < 6; i++) {
-        const double* rowL = L + i * 10;
+        const Ptr rowL = L + i * 10;
         double* rowA = a + i * 4;
         rowA[0] = 2 * rowL[0] * betas[0] + rowL[1] * betas[1] + rowL[3] * betas[2] + rowL[6] * betas[3];
         rowA[1] = rowL[1] * betas[0] + 2 * rowL[2] * betas[1] + rowL[4] * betas[2] + rowL[7] * betas[3];
@@ -554,7 +580,7 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
     // compute_R_and_t: ccs, pcs, sign, Horn/Arun alignment, reprojection error
     for (int i = 0; i < 4; i++) ccs[i][0] = ccs[i][1] = ccs[i][2] = 0.0f;
     for (int i = 0; i < 4; i++) {
-      const double* v = ut + 12 * (11 - i);
+      const Ptr v = ut + 12 * (11 - i);
       for (int j = 0; j < 4; j++)
         for (int k = 0; k < 3; k++) ccs[j][k] += betas[i] * v[3 * j + k];
     }
@@ -639,7 +665,10 @@ __device__ double epnp_compute_pose(int n, const double* pws, const double* us, 
 }
 
 // CheckInliers for correspondence i under (R, t): src/PnPsolver.cc:289-315
-__device__ __forceinline__ bool pnp_is_inlier(const double* Rt, const float* p3, const float* p2, float maxErr, const EpnpCam cam) {
+__device__ __forceinline__ bool pnp_is_inlier(const double* Rt, const float* q /* {u,v,X,Y,Z,maxErr} */, const EpnpCam cam) {
+  const float* p2 = q;
+  const float* p3 = q + 2;
+  const float maxErr = q[5];
   float Xc = (float)(Rt[0] * p3[0] + Rt[1] * p3[1] + Rt[2] * p3[2] + Rt[9]);
   float Yc = (float)(Rt[3] * p3[0] + Rt[4] * p3[1] + Rt[5] * p3[2] + Rt[10]);
   float invZc = (float)(1 / (Rt[6] * p3[0] + Rt[7] * p3[1] + Rt[8] * p3[2] + Rt[11]));
@@ -653,14 +682,12 @@ __device__ __forceinline__ bool pnp_is_inlier(const double* Rt, const float* p3,
 
 __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all,
                                             TrackBuffers tb, TrackCam tcam, const float* __restrict__ sigma2, PnpParams pp) {
-  __shared__ float s_p2[PNP_MAXN * 2];
-  __shared__ float s_p3[PNP_MAXN * 3];
-  __shared__ float s_maxerr[PNP_MAXN];
-  __shared__ uint16_t s_kpidx[PNP_MAXN];
-  __shared__ double s_Rt[64][12];
-  __shared__ unsigned long long s_mask[64][PNP_WORDS];
+  // gathered correspondences live in HBM (read-mostly, L2-resident): {u, v, X, Y, Z, maxErr} f32
+  __shared__ double s_work[PNP_CHUNK * (144 + 60)];   // per-lane EPnP matrices, lane-interleaved
+  __shared__ double s_Rt[PNP_CHUNK][12];
+  __shared__ unsigned long long s_mask[PNP_CHUNK][PNP_WORDS];
   __shared__ unsigned long long s_best[PNP_WORDS], s_ref[PNP_WORDS];
-  __shared__ int s_cnt[64];
+  __shared__ int s_cnt[PNP_CHUNK];
   __shared__ double s_RtRef[12];
   __shared__ double s_mtm[144];
   const int f = blockIdx.x, lane = threadIdx.x;
@@ -674,6 +701,10 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
   float* T_out = tb.pnp_T + (size_t)f * 16;
   const EpnpCam cam = {(double)tcam.ffx, (double)tcam.ffy, (double)tcam.fcx, (double)tcam.fcy};
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  float* g_p = tb.pnp_pts + (size_t)f * cap * 6;
+  uint16_t* g_idx = tb.pnp_kpidx + (size_t)f * cap;
+  const int wl = lane < PNP_CHUNK ? lane : 0;
+  const LArr w_ut{s_work + wl}, w_L{s_work + 144 * PNP_CHUNK + wl};
 
   for (int i = lane; i < cap; i += 64) inl_out[i] = 0;
   // ---- ctor gather, in keypoint order
@@ -686,13 +717,14 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
     const int pos = N + __popcll(bal & lt);
     if (fl && pos < PNP_MAXN) {
       const sd_keypoint kp = kps[i];
-      s_p2[pos * 2] = kp.x;
-      s_p2[pos * 2 + 1] = kp.y;
-      s_maxerr[pos] = sigma2[kp.octave] * pp.th2;
-      s_p3[pos * 3] = (float)Xw[(size_t)m * 3];
-      s_p3[pos * 3 + 1] = (float)Xw[(size_t)m * 3 + 1];
-      s_p3[pos * 3 + 2] = (float)Xw[(size_t)m * 3 + 2];
-      s_kpidx[pos] = (uint16_t)i;
+      float* q = g_p + (size_t)pos * 6;
+      q[0] = kp.x;
+      q[1] = kp.y;
+      q[2] = (float)Xw[(size_t)m * 3];
+      q[3] = (float)Xw[(size_t)m * 3 + 1];
+      q[4] = (float)Xw[(size_t)m * 3 + 2];
+      q[5] = sigma2[kp.octave] * pp.th2;
+      g_idx[pos] = (uint16_t)i;
     }
     N += __popcll(bal);
   }
@@ -726,7 +758,7 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
   const int total = max(maxIts, pp.n_iterations);   // while (mnIterations < maxIts || nCurrent < nIterations)
   const int nwords = (N + 63) >> 6;
   const int32_t* rs = tb.rand_stream + (size_t)f * pp.rand_per_frame;
-  int best = 0;
+  int best = 0, accepted = 0, acc_iters = 0, acc_cnt = 0;
   float bestT[12];
   for (int i = 0; i < 12; i++) bestT[i] = 0.f;
   double* scratch = tb.pnp_scratch + (size_t)f * cap * 12;
@@ -752,14 +784,15 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
           if (modp[q] == randi) { modv[q] = backv; found = true; }
         if (!found) { modp[nmod] = randi; modv[nmod] = backv; nmod++; }
         size--;
-        pws[3 * k] = s_p3[val * 3];
-        pws[3 * k + 1] = s_p3[val * 3 + 1];
-        pws[3 * k + 2] = s_p3[val * 3 + 2];
-        us[2 * k] = s_p2[val * 2];
-        us[2 * k + 1] = s_p2[val * 2 + 1];
+        const float* q = g_p + (size_t)val * 6;
+        pws[3 * k] = q[2];
+        pws[3 * k + 1] = q[3];
+        pws[3 * k + 2] = q[4];
+        us[2 * k] = q[0];
+        us[2 * k + 1] = q[1];
       }
       double R[3][3], t[3];
-      epnp_compute_pose<false>(4, pws, us, alphas, pcs, cam, R, t);
+      epnp_compute_pose<false>(4, pws, us, alphas, pcs, cam, R, t, w_ut, w_L);
       for (int i = 0; i < 9; i++) s_Rt[lane][i] = R[i / 3][i % 3];
       for (int i = 0; i < 3; i++) s_Rt[lane][9 + i] = t[i];
     }
@@ -770,7 +803,7 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
       for (int w = 0; w < nwords; w++) {
         const int i = w * 64 + lane;
         bool in = false;
-        if (i < N) in = pnp_is_inlier(s_Rt[h], &s_p3[i * 3], &s_p2[i * 2], s_maxerr[i], cam);
+        if (i < N) in = pnp_is_inlier(s_Rt[h], g_p + (size_t)i * 6, cam);
         const unsigned long long bal = __ballot(in);
         if (lane == 0) s_mask[h][w] = bal;
         cnt += __popcll(bal);
@@ -796,18 +829,19 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
           int n = 0;
           for (int i = 0; i < N; i++)
             if ((s_best[i >> 6] >> (i & 63)) & 1ull) {
-              pws[3 * n] = s_p3[i * 3];
-              pws[3 * n + 1] = s_p3[i * 3 + 1];
-              pws[3 * n + 2] = s_p3[i * 3 + 2];
-              us[2 * n] = s_p2[i * 2];
-              us[2 * n + 1] = s_p2[i * 2 + 1];
+              const float* q = g_p + (size_t)i * 6;
+              pws[3 * n] = q[2];
+              pws[3 * n + 1] = q[3];
+              pws[3 * n + 2] = q[4];
+              us[2 * n] = q[0];
+              us[2 * n + 1] = q[1];
               n++;
             }
         }
         __syncthreads();
         {
           double R[3][3], t[3];
-          epnp_compute_pose<true>(best, pws, us, alphas, pcs, cam, R, t, s_mtm);   // best == popcount(s_best)
+          epnp_compute_pose<true>(best, pws, us, alphas, pcs, cam, R, t, w_ut, w_L, s_mtm);   // best == popcount(s_best)
           if (lane == 0) {
             for (int i = 0; i < 9; i++) s_RtRef[i] = R[i / 3][i % 3];
             for (int i = 0; i < 3; i++) s_RtRef[9 + i] = t[i];
@@ -818,31 +852,39 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
         for (int w = 0; w < nwords; w++) {
           const int i = w * 64 + lane;
           bool in = false;
-          if (i < N) in = pnp_is_inlier(s_RtRef, &s_p3[i * 3], &s_p2[i * 2], s_maxerr[i], cam);
+          if (i < N) in = pnp_is_inlier(s_RtRef, g_p + (size_t)i * 6, cam);
           const unsigned long long bal = __ballot(in);
           if (lane == 0) s_ref[w] = bal;
           rcnt += __popcll(bal);
         }
         __syncthreads();
-        if (rcnt > minInl) {
-          // accepted: mRefinedTcw, refined inliers scattered to keypoint slots
-          for (int i = lane; i < N; i += 64)
-            if ((s_ref[i >> 6] >> (i & 63)) & 1ull) inl_out[s_kpidx[i]] = 1;
-          if (lane == 0) {
-            for (int r = 0; r < 3; r++) {
-              for (int c = 0; c < 3; c++) T_out[r * 4 + c] = (float)s_RtRef[r * 3 + c];
-              T_out[r * 4 + 3] = (float)s_RtRef[9 + r];
-            }
-            T_out[12] = T_out[13] = T_out[14] = 0.f;
-            T_out[15] = 1.f;
-            info[0] = 1; info[1] = rcnt; info[2] = 0; info[3] = c0 + h + 1; info[7] = 1;
-          }
-          return;
+        if (rcnt > minInl) {   // accepted: mRefinedTcw / mvbRefinedInliers are returned (written in the common tail)
+          accepted = 1;
+          acc_iters = c0 + h + 1;
+          acc_cnt = rcnt;
         }
       }
       // cnt >= minInl but no new best: Refine() would refit the same best set and fail again
+      if (accepted) break;
     }
     __syncthreads();
+    if (accepted) break;
+  }
+  // ---- common tail (uniform control flow): write the returned pose and inlier flags
+  __syncthreads();
+  if (accepted) {
+    for (int i = lane; i < N; i += 64)
+      if ((s_ref[i >> 6] >> (i & 63)) & 1ull) inl_out[g_idx[i]] = 1;
+    if (lane == 0) {
+      for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T_out[r * 4 + c] = (float)s_RtRef[r * 3 + c];
+        T_out[r * 4 + 3] = (float)s_RtRef[9 + r];
+      }
+      T_out[12] = T_out[13] = T_out[14] = 0.f;
+      T_out[15] = 1.f;
+      info[0] = 1; info[1] = acc_cnt; info[2] = 0; info[3] = acc_iters; info[7] = 1;
+    }
+    return;
   }
   // ---- iterations exhausted
   if (lane == 0) {
@@ -851,7 +893,7 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
   }
   if (best >= minInl) {
     for (int i = lane; i < N; i += 64)
-      if ((s_best[i >> 6] >> (i & 63)) & 1ull) inl_out[s_kpidx[i]] = 1;
+      if ((s_best[i >> 6] >> (i & 63)) & 1ull) inl_out[g_idx[i]] = 1;
     if (lane == 0) {
       for (int r = 0; r < 3; r++) {
         for (int c = 0; c < 3; c++) T_out[r * 4 + c] = bestT[r * 3 + c];
@@ -869,7 +911,8 @@ __global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_
 __global__ void k_epnp_debug(int n, const double* pws, const double* us, double* work, EpnpCam cam, double* out13) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double R[3][3], t[3];
-  double e = epnp_compute_pose<false>(n, pws, us, work, work + 4 * (size_t)n, cam, R, t);
+  double ut[144], L[60];
+  double e = epnp_compute_pose<false>(n, pws, us, work, work + 4 * (size_t)n, cam, R, t, (double*)ut, (double*)L);
   for (int i = 0; i < 9; i++) out13[i] = R[i / 3][i % 3];
   for (int i = 0; i < 3; i++) out13[9 + i] = t[i];
   out13[12] = e;
