@@ -63,16 +63,11 @@ __device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t* p) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void k_pyr_level(const OrbPlan* __restrict__ P, int level,
-                                                   const uint8_t* __restrict__ src0, int src_stride,
-                                                   size_t src_frame_stride, uint8_t* __restrict__ pyr,
-                                                   const int32_t* __restrict__ coef) {
-  const LevelGeom L = P->lv[level];
-  const int frame = blockIdx.z;
-  const int px = (blockIdx.x * 64 + threadIdx.x) * 4;
-  const int py = blockIdx.y * 4 + threadIdx.y;
-  if (px >= L.pstride || py >= L.prows) return;
-  uint8_t* dstbase = pyr + (size_t)frame * P->pyr_frame_bytes + L.off;
+#define PYR_ROWS 1   // rows per thread (a multi-row variant mis-compared on the bilinear path; kept at 1 until understood)
+
+__device__ __forceinline__ uint32_t pyr_px4(const OrbPlan* __restrict__ P, const LevelGeom& L, int level, int frame, int px, int py,
+                                            const uint8_t* __restrict__ src0, int src_stride, size_t src_frame_stride,
+                                            const uint8_t* __restrict__ pyr, const int32_t* __restrict__ coef) {
   const int Y = reflect101(py - SD_EDGE, L.h);
   // fast path: the 4 outputs are interior pixels X0..X0+3 (no reflection, consecutive sources)
   const int X0 = px - SD_EDGE;
@@ -188,7 +183,28 @@ __global__ __launch_bounds__(256) void k_pyr_level(const OrbPlan* __restrict__ P
       }
     }
   }
-  *(uint32_t*)(dstbase + (size_t)py * L.pstride + px) = packed;
+  return packed;
+}
+
+__global__ __launch_bounds__(256) void k_pyr_level(const OrbPlan* __restrict__ P, int level,
+                                                   const uint8_t* __restrict__ src0, int src_stride,
+                                                   size_t src_frame_stride, uint8_t* __restrict__ pyr,
+                                                   const int32_t* __restrict__ coef) {
+  const LevelGeom L = P->lv[level];
+  const int frame = blockIdx.z;
+  const int px = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int py0 = (blockIdx.y * 4 + threadIdx.y) * PYR_ROWS;
+  if (px >= L.pstride || py0 >= L.prows) return;
+  uint8_t* dstbase = pyr + (size_t)frame * P->pyr_frame_bytes + L.off;
+  uint32_t out[PYR_ROWS];
+#pragma unroll
+  for (int r = 0; r < PYR_ROWS; r++) {
+    const int py = min(py0 + r, L.prows - 1);   // clamped duplicates are computed but not stored
+    out[r] = pyr_px4(P, L, level, frame, px, py, src0, src_stride, src_frame_stride, pyr, coef);
+  }
+#pragma unroll
+  for (int r = 0; r < PYR_ROWS; r++)
+    if (py0 + r < L.prows) *(uint32_t*)(dstbase + (size_t)(py0 + r) * L.pstride + px) = out[r];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -200,12 +216,10 @@ __global__ __launch_bounds__(256) void k_pyr_level(const OrbPlan* __restrict__ P
 // The cell (+3 px ring halo) is staged once through LDS in aligned 4-byte words; scores live in
 // a byte map in LDS; ordered emission uses wave ballots over wave-contiguous pixel ranges.
 // ------------------------------------------------------------------------------------------
-// Full FAST-9/16 decision + score for one pixel whose 7x7 neighbourhood is in LDS.
-// Returns 0 when the pixel is not a corner, else cornerScore<16> (>= threshold).
-__device__ __forceinline__ int fast_score(const uint8_t* __restrict__ c, int tp, int th) {
-  // ring offsets (dx,dy), clockwise from (0,3): SURVEY App. A1
+// FAST-9/16 on one pixel whose 7x7 neighbourhood is in LDS: ring differences d[k] = v - p[k]
+// (ring offsets (dx,dy) clockwise from (0,3): SURVEY App. A1).
+__device__ __forceinline__ void fast_ring(const uint8_t* __restrict__ c, int tp, int d[16]) {
   const int v = c[0];
-  int d[16];
   d[0] = v - c[3 * tp];
   d[1] = v - c[3 * tp + 1];
   d[2] = v - c[2 * tp + 2];
@@ -222,13 +236,18 @@ __device__ __forceinline__ int fast_score(const uint8_t* __restrict__ c, int tp,
   d[13] = v - c[tp - 3];
   d[14] = v - c[2 * tp - 2];
   d[15] = v - c[3 * tp - 1];
+}
+
+// corner test: >= 9 contiguous ring pixels darker than v - th or brighter than v + th
+__device__ __forceinline__ bool fast_is_corner(const uint8_t* __restrict__ c, int tp, int th) {
+  int d[16];
+  fast_ring(c, tp, d);
   unsigned dark = 0, bright = 0;   // dark: p < v - th  <=> d > th ; bright: p > v + th <=> d < -th
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     dark |= (unsigned)(d[k] > th) << k;
     bright |= (unsigned)(d[k] < -th) << k;
   }
-  // >= 9 contiguous set bits on the 16-ring (wrap-around)
   unsigned md = dark | (dark << 16), mb = bright | (bright << 16);
   unsigned rd = md & (md >> 1);
   rd &= rd >> 2;
@@ -238,8 +257,13 @@ __device__ __forceinline__ int fast_score(const uint8_t* __restrict__ c, int tp,
   rb &= rb >> 2;
   rb &= rb >> 4;
   rb &= mb >> 8;
-  if (((rd | rb) & 0xffffu) == 0) return 0;
-  // score = max(max_arc min d, max_arc min(-d)) - 1  (== cornerScore<16>; >= th for a corner)
+  return ((rd | rb) & 0xffffu) != 0;
+}
+
+// cornerScore<16>: max over the 16 nine-arcs of min(d) / min(-d), minus 1 (>= th for a corner)
+__device__ __forceinline__ int fast_corner_score(const uint8_t* __restrict__ c, int tp) {
+  int d[16];
+  fast_ring(c, tp, d);
   int m2[16], m4[16], M2[16], M4[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
@@ -266,8 +290,9 @@ __device__ __forceinline__ int fast_score(const uint8_t* __restrict__ c, int tp,
 //   A. every wave owns a contiguous band of rows; per 64-px row segment a 4-read compass test
 //      (a 9-arc always contains two ADJACENT compass points of the same polarity) rejects most
 //      pixels; survivors are appended, in raster order, to the wave's LDS queue (ballot prefix);
-//   B. the queue is processed densely (all lanes busy): full ring classification + score;
-//   C. after a block barrier, NMS on the queued pixels against the LDS score map, then ordered
+//   B. the queue is processed densely (all lanes busy): full ring classification; true corners
+//      are re-compacted in place (still raster order) and scored densely in a second pass;
+//   C. after a block barrier, NMS on the queued corners against the LDS score map, then ordered
 //      emission (wave bands are contiguous in raster order, so per-wave counts give offsets).
 __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ P,
                                                     const CellGeom* __restrict__ cells,
@@ -340,13 +365,29 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
         qn += __popcll(m);
       }
     }
-    // ---- B: full test + score on the queued pixels
+    // ---- B1: full 9-contiguous test on the queued pixels; corners re-compacted in place
+    int cn = 0;
+    for (int e0 = 0; e0 < qn; e0 += 64) {
+      const int e = e0 + lane;
+      bool corner = false;
+      unsigned q = 0;
+      if (e < qn) {
+        q = queue[e];
+        const int y = (int)__umulhi(q, magic), x = (int)q - y * zw;
+        corner = fast_is_corner(tile + (y + 3) * TP + x + 3 + sh, TP, th);
+      }
+      const unsigned long long m = __ballot(corner);   // all reads of this chunk precede the writes (cn <= e0)
+      if (corner) queue[cn + __popcll(m & lt)] = (uint16_t)q;
+      cn += __popcll(m);
+    }
+    qn = cn;
+    // ---- B2: scores of the corners (dense)
     for (int e0 = 0; e0 < qn; e0 += 64) {
       const int e = e0 + lane;
       if (e < qn) {
         const unsigned q = queue[e];
         const int y = (int)__umulhi(q, magic), x = (int)q - y * zw;
-        const int s = fast_score(tile + (y + 3) * TP + x + 3 + sh, TP, th);
+        const int s = fast_corner_score(tile + (y + 3) * TP + x + 3 + sh, TP);
         if (s > 0) sc[(y + 1) * SP + x + 1] = (uint8_t)s;
       }
     }
@@ -407,9 +448,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
 //   4. level-wide retainBest + resize       :601-604   (lane 0)
 // Candidate lists are staged in LDS when the level fits, else processed in place in HBM.
 // ------------------------------------------------------------------------------------------
-#define SEL_WORK_CAP 8192
-#define SEL_LIST_CAP 4096
-#define SEL_MAX_CELLS 1024
+// LDS budget ~28 KB per workgroup (5 per CU); denser levels fall back to in-place HBM lists
+#define SEL_WORK_CAP 4096
+#define SEL_LIST_CAP 1536
+#define SEL_MAX_CELLS 512
 
 __global__ __launch_bounds__(256) void k_select_level(const OrbPlan* __restrict__ P,
                                                       const CellGeom* __restrict__ cells,
@@ -675,13 +717,15 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
   {
     const int u = (lane & 31) - 15;
     const int half = lane >> 5;   // 0: rows +v, 1: rows -v
-    if ((lane & 31) < 31) {
-      for (int v = half; v <= 15; v++) {   // half 1 skips v = 0
-        if (abs(u) <= c_umax[v]) {
-          int val = half ? center[u - v * step] : center[u + v * step];
-          m10 += u * val;
-          m01 += (half ? -v : v) * val;
-        }
+    const bool act = (lane & 31) < 31;
+    const int au = abs(u);
+    const int sstep = half ? -step : step;
+#pragma unroll
+    for (int v = 0; v <= 15; v++) {   // fully unrolled: the 16 row loads are independent and issue back to back
+      if (act && au <= c_umax[v] && !(half && v == 0)) {
+        const int val = center[u + v * sstep];
+        m10 += u * val;
+        m01 += (half ? -v : v) * val;
       }
     }
 #pragma unroll
@@ -800,7 +844,7 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[0], s));
   for (int l = 0; l < P.nlevels; l++) {
     const LevelGeom& L = P.lv[l];
-    dim3 grid((L.pstride + 255) / 256, (L.prows + 3) / 4, n), block(64, 4, 1);
+    dim3 grid((L.pstride + 255) / 256, (L.prows + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), n), block(64, 4, 1);
     hipLaunchKernelGGL(k_pyr_level, grid, block, 0, s, h->d_plan, l, d_imgs, stride, frame_stride, h->d_pyr, h->d_coef);
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], s));
