@@ -63,7 +63,22 @@ __device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t* p) {
   return v;
 }
 
-#define PYR_ROWS 1   // rows per thread (a multi-row variant mis-compared on the bilinear path; kept at 1 until understood)
+// 16-byte window starting at the 4-byte-aligned address at or below p, as two 64-bit halves;
+// *sh = p's offset inside the window (0..3).  Aligned dword loads only: byte-unaligned vector
+// loads are legal on gfx950 but ran the bilinear level kernels at ~270 GB/s.
+__device__ __forceinline__ void ld_window16(const uint8_t* p, unsigned long long* lo, unsigned long long* hi, int* sh) {
+  const uintptr_t a = (uintptr_t)p;
+  const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+  *sh = (int)(a & 3);
+  const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+  *lo = w0 | ((unsigned long long)w1 << 32);
+  *hi = w2 | ((unsigned long long)w3 << 32);
+}
+__device__ __forceinline__ int win_byte(unsigned long long lo, unsigned long long hi, int b) {   // b in 0..15
+  return b < 8 ? (int)((lo >> (8 * b)) & 0xff) : (int)((hi >> (8 * (b - 8))) & 0xff);
+}
+
+#define PYR_ROWS 1   // rows per thread (multi-row unrolling bought nothing and tripped a codegen problem in the byte packing)
 
 __device__ __forceinline__ uint32_t pyr_px4(const OrbPlan* __restrict__ P, const LevelGeom& L, int level, int frame, int px, int py,
                                             const uint8_t* __restrict__ src0, int src_stride, size_t src_frame_stride,
@@ -75,7 +90,13 @@ __device__ __forceinline__ uint32_t pyr_px4(const OrbPlan* __restrict__ P, const
   uint32_t packed = 0;
   if (level == 0) {
     const uint8_t* s = src0 + (size_t)frame * src_frame_stride + (size_t)Y * src_stride;
-    if (interior) {
+    if (interior && X0 >= 4 && X0 + 7 < L.w) {   // aligned window stays inside this source row
+      const uintptr_t a = (uintptr_t)(s + X0);
+      const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+      const int sh = (int)(a & 3) * 8;
+      const unsigned long long w = q[0] | ((unsigned long long)q[1] << 32);
+      packed = (uint32_t)(w >> sh);
+    } else if (interior) {
       packed = ld_u32_unaligned(s + X0);
     } else {
 #pragma unroll
@@ -137,22 +158,17 @@ __device__ __forceinline__ uint32_t pyr_px4(const OrbPlan* __restrict__ P, const
           al[k] = xa[X0 + k];
         }
         const int base = sx[0];
-        if (sx[3] + 1 - base <= 11 && base + 11 < S.w + SD_EDGE) {   // window stays inside the padded row
-          uint32_t w0[3], w1[3];
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            w0[j] = ld_u32_unaligned(r0 + base + 4 * j);
-            w1[j] = ld_u32_unaligned(r1 + base + 4 * j);
-          }
-          const unsigned long long lo0 = w0[0] | ((unsigned long long)w0[1] << 32), lo1 = w1[0] | ((unsigned long long)w1[1] << 32);
+        if (sx[3] + 1 - base <= 11 && base + 15 < S.w + SD_EDGE) {   // 16-byte aligned window stays inside the padded row
+          unsigned long long lo0, hi0, lo1, hi1;
+          int sh0, sh1;
+          ld_window16(r0 + base, &lo0, &hi0, &sh0);
+          ld_window16(r1 + base, &lo1, &hi1, &sh1);   // sh1 == sh0 (row pitch is a multiple of 64)
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const int o = sx[k] - base;            // 0..10
             const int o1 = (sx[k] + 1 < S.w ? sx[k] + 1 : S.w - 1) - base;
-            const int p00 = o < 8 ? (int)((lo0 >> (8 * o)) & 0xff) : (int)((w0[2] >> (8 * (o - 8))) & 0xff);
-            const int p01 = o1 < 8 ? (int)((lo0 >> (8 * o1)) & 0xff) : (int)((w0[2] >> (8 * (o1 - 8))) & 0xff);
-            const int p10 = o < 8 ? (int)((lo1 >> (8 * o)) & 0xff) : (int)((w1[2] >> (8 * (o - 8))) & 0xff);
-            const int p11 = o1 < 8 ? (int)((lo1 >> (8 * o1)) & 0xff) : (int)((w1[2] >> (8 * (o1 - 8))) & 0xff);
+            const int p00 = win_byte(lo0, hi0, sh0 + o), p01 = win_byte(lo0, hi0, sh0 + o1);
+            const int p10 = win_byte(lo1, hi1, sh1 + o), p11 = win_byte(lo1, hi1, sh1 + o1);
             const int a0 = (int)(short)(al[k] & 0xffff), a1 = (int)(short)((unsigned)al[k] >> 16);
             const int h0 = p00 * a0 + p01 * a1;
             const int h1 = p10 * a0 + p11 * a1;
