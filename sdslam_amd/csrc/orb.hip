@@ -74,15 +74,32 @@ __device__ __forceinline__ void ld_window16(const uint8_t* p, unsigned long long
   *lo = w0 | ((unsigned long long)w1 << 32);
   *hi = w2 | ((unsigned long long)w3 << 32);
 }
+// cv::resize INTER_LINEAR coefficients of destination index d (OpenCV 3.2):
+// fx = (float)((d + 0.5) * scale - 0.5); s = floor(fx); fx -= s; alpha = saturate_cast<short>(w * 2048).
+// Recomputed per pixel (a handful of IEEE ops, bit-identical to the host tables) so that the
+// pixel loads do not wait behind a dependent table load.
+__device__ __forceinline__ void resize_coef(int d, double scale, int sn, bool clamp, int* s_out, int* a0, int* a1) {
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (clamp) {
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= sn - 1) { f = 0.f; s = sn - 1; }
+  }
+  *s_out = s;
+  *a0 = (int)rintf((1.f - f) * 2048.f);
+  *a1 = (int)rintf(f * 2048.f);
+}
+
 __device__ __forceinline__ int win_byte(unsigned long long lo, unsigned long long hi, int b) {   // b in 0..15
   return b < 8 ? (int)((lo >> (8 * b)) & 0xff) : (int)((hi >> (8 * (b - 8))) & 0xff);
 }
 
 #define PYR_ROWS 1   // rows per thread (multi-row unrolling bought nothing and tripped a codegen problem in the byte packing)
 
-__device__ __forceinline__ uint32_t pyr_px4(const OrbPlan* __restrict__ P, const LevelGeom& L, int level, int frame, int px, int py,
-                                            const uint8_t* __restrict__ src0, int src_stride, size_t src_frame_stride,
-                                            const uint8_t* __restrict__ pyr, const int32_t* __restrict__ coef) {
+__device__ __forceinline__ uint32_t pyr_px4(const LevelGeom& L, const LevelGeom& S, size_t pyr_frame_bytes, int level, int frame, int px,
+                                            int py, const uint8_t* __restrict__ src0, int src_stride, size_t src_frame_stride,
+                                            const uint8_t* __restrict__ pyr) {
   const int Y = reflect101(py - SD_EDGE, L.h);
   // fast path: the 4 outputs are interior pixels X0..X0+3 (no reflection, consecutive sources)
   const int X0 = px - SD_EDGE;
@@ -108,8 +125,7 @@ __device__ __forceinline__ uint32_t pyr_px4(const OrbPlan* __restrict__ P, const
       }
     }
   } else {
-    const LevelGeom S = P->lv[level - 1];
-    const uint8_t* sb = pyr + (size_t)frame * P->pyr_frame_bytes + S.off + (size_t)SD_EDGE * S.pstride + SD_EDGE;
+    const uint8_t* sb = pyr + (size_t)frame * pyr_frame_bytes + S.off + (size_t)SD_EDGE * S.pstride + SD_EDGE;
     if (L.area2x2) {
       const uint8_t* r0 = sb + (size_t)(2 * Y) * S.pstride;
       const uint8_t* r1 = r0 + S.pstride;
@@ -136,27 +152,20 @@ __device__ __forceinline__ uint32_t pyr_px4(const OrbPlan* __restrict__ P, const
         }
       }
     } else {
-      const int32_t* xo = coef + L.cx;
-      const int32_t* xa = xo + L.w;
-      const int32_t* yo = coef + L.cy;
-      const int32_t* yb = yo + L.h;
-      int sy0 = yo[Y], sy1 = sy0 + 1;
+      int sy0, b0, b1;
+      resize_coef(Y, L.scale_y, S.h, false, &sy0, &b0, &b1);
+      int sy1 = sy0 + 1;
       sy0 = sy0 < 0 ? 0 : (sy0 < S.h ? sy0 : S.h - 1);
       sy1 = sy1 < 0 ? 0 : (sy1 < S.h ? sy1 : S.h - 1);
-      const int bb = yb[Y];
-      const int b0 = (int)(short)(bb & 0xffff), b1 = (int)(short)((unsigned)bb >> 16);
-      const uint8_t* r0 = sb + (size_t)sy0 * S.pstride;
-      const uint8_t* r1 = sb + (size_t)sy1 * S.pstride;
+      const uint8_t* r0 = sb + (size_t)__mul24(sy0, S.pstride);
+      const uint8_t* r1 = sb + (size_t)__mul24(sy1, S.pstride);
       bool done = false;
       if (interior) {
         // the sources of 4 consecutive outputs span <= 12 bytes for scale factors up to 2:
         // fetch each source row as three dwords and pick bytes out of the registers
-        int sx[4], al[4];
+        int sx[4], wa0[4], wa1[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          sx[k] = xo[X0 + k];
-          al[k] = xa[X0 + k];
-        }
+        for (int k = 0; k < 4; k++) resize_coef(X0 + k, L.scale_x, S.w, true, &sx[k], &wa0[k], &wa1[k]);
         const int base = sx[0];
         if (sx[3] + 1 - base <= 11 && base + 15 < S.w + SD_EDGE) {   // 16-byte aligned window stays inside the padded row
           unsigned long long lo0, hi0, lo1, hi1;
@@ -169,10 +178,11 @@ __device__ __forceinline__ uint32_t pyr_px4(const OrbPlan* __restrict__ P, const
             const int o1 = (sx[k] + 1 < S.w ? sx[k] + 1 : S.w - 1) - base;
             const int p00 = win_byte(lo0, hi0, sh0 + o), p01 = win_byte(lo0, hi0, sh0 + o1);
             const int p10 = win_byte(lo1, hi1, sh1 + o), p11 = win_byte(lo1, hi1, sh1 + o1);
-            const int a0 = (int)(short)(al[k] & 0xffff), a1 = (int)(short)((unsigned)al[k] >> 16);
-            const int h0 = p00 * a0 + p01 * a1;
-            const int h1 = p10 * a0 + p11 * a1;
-            const int ov = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            const int a0 = wa0[k], a1 = wa1[k];
+            // all factors fit 24 bits: v_mul_i32_i24 / v_mad_i32_i24 issue at full rate, v_mul_lo_u32 at a quarter
+            const int h0 = __mul24(p00, a0) + __mul24(p01, a1);
+            const int h1 = __mul24(p10, a0) + __mul24(p11, a1);
+            const int ov = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
             packed |= (uint32_t)(ov < 0 ? 0 : (ov > 255 ? 255 : ov)) << (8 * k);
           }
           done = true;
@@ -185,13 +195,12 @@ __device__ __forceinline__ uint32_t pyr_px4(const OrbPlan* __restrict__ P, const
           uint32_t v = 0;
           if (x < L.w + 2 * SD_EDGE) {
             int X = reflect101(x - SD_EDGE, L.w);
-            int sx = xo[X];
+            int sx, a0, a1;
+            resize_coef(X, L.scale_x, S.w, true, &sx, &a0, &a1);
             int sx1 = sx + 1 < S.w ? sx + 1 : S.w - 1;
-            int aa = xa[X];
-            int a0 = (int)(short)(aa & 0xffff), a1 = (int)(short)((unsigned)aa >> 16);
-            int h0 = r0[sx] * a0 + r0[sx1] * a1;
-            int h1 = r1[sx] * a0 + r1[sx1] * a1;
-            int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            int h0 = __mul24(r0[sx], a0) + __mul24(r0[sx1], a1);
+            int h1 = __mul24(r1[sx], a0) + __mul24(r1[sx1], a1);
+            int o = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
             v = (uint32_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
           }
           packed |= v << (8 * k);
@@ -202,21 +211,21 @@ __device__ __forceinline__ uint32_t pyr_px4(const OrbPlan* __restrict__ P, const
   return packed;
 }
 
-__global__ __launch_bounds__(256) void k_pyr_level(const OrbPlan* __restrict__ P, int level,
+// L / S (this level, source level) travel by value in the kernel arguments: one less dependent
+// load before the first pixel fetch.
+__global__ __launch_bounds__(256) void k_pyr_level(const LevelGeom L, const LevelGeom S, size_t pyr_frame_bytes, int level,
                                                    const uint8_t* __restrict__ src0, int src_stride,
-                                                   size_t src_frame_stride, uint8_t* __restrict__ pyr,
-                                                   const int32_t* __restrict__ coef) {
-  const LevelGeom L = P->lv[level];
+                                                   size_t src_frame_stride, uint8_t* __restrict__ pyr) {
   const int frame = blockIdx.z;
   const int px = (blockIdx.x * 64 + threadIdx.x) * 4;
   const int py0 = (blockIdx.y * 4 + threadIdx.y) * PYR_ROWS;
   if (px >= L.pstride || py0 >= L.prows) return;
-  uint8_t* dstbase = pyr + (size_t)frame * P->pyr_frame_bytes + L.off;
+  uint8_t* dstbase = pyr + (size_t)frame * pyr_frame_bytes + L.off;
   uint32_t out[PYR_ROWS];
 #pragma unroll
   for (int r = 0; r < PYR_ROWS; r++) {
     const int py = min(py0 + r, L.prows - 1);   // clamped duplicates are computed but not stored
-    out[r] = pyr_px4(P, L, level, frame, px, py, src0, src_stride, src_frame_stride, pyr, coef);
+    out[r] = pyr_px4(L, S, pyr_frame_bytes, level, frame, px, py, src0, src_stride, src_frame_stride, pyr);
   }
 #pragma unroll
   for (int r = 0; r < PYR_ROWS; r++)
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
       const uint8_t* g = img + (size_t)(C.zy0 + sr0 - 3 + SD_EDGE) * L.pstride + xa;
       for (int row = wave; row < npr; row += 4)
         for (int wc = lane; wc < TPW; wc += 64)
-          ((uint32_t*)tile)[row * TPW + wc] = *(const uint32_t*)(g + (size_t)row * L.pstride + wc * 4);
+          ((uint32_t*)tile)[__mul24(row, TPW) + wc] = *(const uint32_t*)(g + (size_t)__mul24(row, L.pstride) + wc * 4);
       const int nsc = ((nsr + 2) * SP) >> 2;
       for (int i = tid; i < nsc; i += 256) ((uint32_t*)sc)[i] = 0;
     }
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
     const int y_lo = min(wave * rpw, nsr), y_hi = min(y_lo + rpw, nsr);
     int qn = 0;
     for (int y = y_lo; y < y_hi; y++) {
-      const uint8_t* rowc = tile + (y + 3) * TP + 3 + sh;
+      const uint8_t* rowc = tile + __mul24(y + 3, TP) + 3 + sh;
       for (int x0 = 0; x0 < zw; x0 += 64) {
         const int x = x0 + lane;
         bool pass = false;
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
           pass = ((dk & dr) | (br & brr)) != 0;
         }
         const unsigned long long m = __ballot(pass);
-        if (pass) queue[qn + __popcll(m & lt)] = (uint16_t)(y * zw + x);
+        if (pass) queue[qn + __popcll(m & lt)] = (uint16_t)(__mul24(y, zw) + x);
         qn += __popcll(m);
       }
     }
@@ -389,8 +398,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
       unsigned q = 0;
       if (e < qn) {
         q = queue[e];
-        const int y = (int)__umulhi(q, magic), x = (int)q - y * zw;
-        corner = fast_is_corner(tile + (y + 3) * TP + x + 3 + sh, TP, th);
+        const int y = (int)__umulhi(q, magic), x = (int)q - __mul24(y, zw);
+        corner = fast_is_corner(tile + __mul24(y + 3, TP) + x + 3 + sh, TP, th);
       }
       const unsigned long long m = __ballot(corner);   // all reads of this chunk precede the writes (cn <= e0)
       if (corner) queue[cn + __popcll(m & lt)] = (uint16_t)q;
@@ -402,9 +411,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
       const int e = e0 + lane;
       if (e < qn) {
         const unsigned q = queue[e];
-        const int y = (int)__umulhi(q, magic), x = (int)q - y * zw;
-        const int s = fast_corner_score(tile + (y + 3) * TP + x + 3 + sh, TP);
-        if (s > 0) sc[(y + 1) * SP + x + 1] = (uint8_t)s;
+        const int y = (int)__umulhi(q, magic), x = (int)q - __mul24(y, zw);
+        const int s = fast_corner_score(tile + __mul24(y + 3, TP) + x + 3 + sh, TP);
+        if (s > 0) sc[__mul24(y + 1, SP) + x + 1] = (uint8_t)s;
       }
     }
     __syncthreads();
@@ -418,10 +427,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
         bool keep = false;
         if (e < qn) {
           const unsigned q = queue[e];
-          const int y = (int)__umulhi(q, magic), x = (int)q - y * zw;
+          const int y = (int)__umulhi(q, magic), x = (int)q - __mul24(y, zw);
           const int yz = sr0 + y;
           if (yz >= r0 && yz < r1) {
-            const uint8_t* p = sc + (y + 1) * SP + x + 1;
+            const uint8_t* p = sc + __mul24(y + 1, SP) + x + 1;
             const int s = p[0];
             keep = s > 0 && s > p[-1] && s > p[1] && s > p[-SP - 1] && s > p[-SP] && s > p[-SP + 1] &&
                    s > p[SP - 1] && s > p[SP] && s > p[SP + 1];
@@ -441,8 +450,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
         const unsigned long long m = __ballot(keep);
         if (keep) {
           const unsigned q = queue[j * 64 + lane];
-          const int y = (int)__umulhi(q, magic), x = (int)q - y * zw;
-          const int s = sc[(y + 1) * SP + x + 1];
+          const int y = (int)__umulhi(q, magic), x = (int)q - __mul24(y, zw);
+          const int s = sc[__mul24(y + 1, SP) + x + 1];
           const unsigned pos = (unsigned)(base + __popcll(m & lt));
           if (pos < C.cap)
             out[pos] = ((uint32_t)s << 24) | ((uint32_t)(C.zy0 + sr0 + y) << 12) | (uint32_t)(C.zx0 + x);
@@ -639,14 +648,14 @@ __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, con
       }
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        ring[r % 7][k] = 18 * (b[k] + b[k + 6]) + 34 * (b[k + 1] + b[k + 5]) + 49 * (b[k + 2] + b[k + 4]) + 55 * b[k + 3];
+        ring[r % 7][k] = __mul24(18, b[k] + b[k + 6]) + __mul24(34, b[k + 1] + b[k + 5]) + __mul24(49, b[k + 2] + b[k + 4]) + __mul24(55, b[k + 3]);
       if (r >= 6) {
         // output row r-6 uses row-pass results of input rows r-6 .. r (ring slots (r-6+i) % 7)
         uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          int s = 18 * (ring[(r - 6) % 7][k] + ring[r % 7][k]) + 34 * (ring[(r - 5) % 7][k] + ring[(r - 1) % 7][k]) +
-                  49 * (ring[(r - 4) % 7][k] + ring[(r - 2) % 7][k]) + 55 * ring[(r - 3) % 7][k];
+          int s = __mul24(18, ring[(r - 6) % 7][k] + ring[r % 7][k]) + __mul24(34, ring[(r - 5) % 7][k] + ring[(r - 1) % 7][k]) +
+                  __mul24(49, ring[(r - 4) % 7][k] + ring[(r - 2) % 7][k]) + __mul24(55, ring[(r - 3) % 7][k]);
           int v = (s + (1 << 15)) >> 16;
           v = v > 255 ? 255 : v;
           packed |= (uint32_t)v << (8 * k);
@@ -766,7 +775,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
     // center[cvRound(x*b + y*a)*step + cvRound(x*a - y*b)]
     const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
     const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
-    const int t0 = bc[r0 * step + q0], t1 = bc[r1 * step + q1];
+    const int t0 = bc[__mul24(r0, step) + q0], t1 = bc[__mul24(r1, step) + q1];
     words[j] = __ballot(t0 < t1);
   }
   if (lane < 4) {
@@ -861,7 +870,8 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   for (int l = 0; l < P.nlevels; l++) {
     const LevelGeom& L = P.lv[l];
     dim3 grid((L.pstride + 255) / 256, (L.prows + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), n), block(64, 4, 1);
-    hipLaunchKernelGGL(k_pyr_level, grid, block, 0, s, h->d_plan, l, d_imgs, stride, frame_stride, h->d_pyr, h->d_coef);
+    hipLaunchKernelGGL(k_pyr_level, grid, block, 0, s, L, P.lv[l > 0 ? l - 1 : 0], (size_t)P.pyr_frame_bytes, l, d_imgs, stride,
+                       frame_stride, h->d_pyr);
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], s));
   if (P.ncells > 0) {

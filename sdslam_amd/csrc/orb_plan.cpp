@@ -107,9 +107,12 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
     // resize tables (level l from level l-1)
     L.area2x2 = 0;
     L.cx = L.cy = 0;
+    L.scale_x = L.scale_y = 1.0;
     if (l > 0) {
       const LevelGeom& S = P.lv[l - 1];
       double sx = 1. / ((double)L.w / S.w), sy = 1. / ((double)L.h / S.h);
+      L.scale_x = sx;
+      L.scale_y = sy;
       int isx = cv_round(sx), isy = cv_round(sy);
       bool fast = std::fabs(sx - isx) < DBL_EPSILON && std::fabs(sy - isy) < DBL_EPSILON;
       if (fast && isx == 2 && isy == 2) {
