@@ -611,7 +611,8 @@ __global__ __launch_bounds__(256) void k_select_level(const OrbPlan* __restrict_
 // Register sliding window, no LDS: a thread owns 4 adjacent output columns of a 32-row band,
 // reads each input row as 3 aligned dwords (12 bytes cover the 4+6 taps), keeps the last 7
 // row-pass results in registers and emits one packed 4-byte store per row.  Only levels that
-// own keypoints are blurred (src/ORBextractor.cc:655-660).
+// own keypoints are blurred by the reference (src/ORBextractor.cc:655-660); here every level is
+// (the blurred image is not an output), which frees the stage from waiting for the selection.
 // ------------------------------------------------------------------------------------------
 #define BLUR_RB 32                  // output rows per wave
 #define BLUR_TW 256                 // output columns per workgroup (64 lanes x 4)
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, con
                                               const int32_t* __restrict__ sel_count) {
   const BlurTile T = tiles[blockIdx.x];
   const int frame = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (sel_count[(size_t)frame * P->nlevels + T.level] <= 0) return;
+  (void)sel_count;   // every level is blurred: the stage then depends on the pyramid only and overlaps FAST/selection
   const LevelGeom L = P->lv[T.level];
   const int x0 = T.tx * BLUR_TW + lane * 4;
   const int y0 = T.ty * BLUR_TH + wave * BLUR_RB;
@@ -874,6 +875,14 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
                        frame_stride, h->d_pyr);
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], s));
+  // blur on the auxiliary stream, beside FAST + selection
+  SD_HIP_CHECK(hipEventRecord(h->ev_pyr_done, s));
+  SD_HIP_CHECK(hipStreamWaitEvent(h->aux_stream, h->ev_pyr_done, 0));
+  if (prof) SD_HIP_CHECK(hipEventRecord(ev[3], h->aux_stream));
+  hipLaunchKernelGGL(k_blur, dim3((unsigned)hp.blur_tiles.size(), n), dim3(256), 0, h->aux_stream, h->d_plan, h->d_tiles, h->d_pyr,
+                     h->d_blur, h->d_sel_count);
+  if (prof) SD_HIP_CHECK(hipEventRecord(ev[6], h->aux_stream));
+  SD_HIP_CHECK(hipEventRecord(h->ev_blur_done, h->aux_stream));
   if (P.ncells > 0) {
     hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, n), dim3(256), hp.fast_lds_bytes, s, h->d_plan, h->d_cells,
                        h->d_pyr, h->d_cand, h->d_cell_count);
@@ -881,9 +890,9 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[2], s));
   hipLaunchKernelGGL(k_select_level, dim3(P.nlevels, n), dim3(256), 0, s, h->d_plan, h->d_cells, h->d_cand,
                      h->d_cell_count, h->d_scratch, h->d_sel, h->d_sel_count);
-  if (prof) SD_HIP_CHECK(hipEventRecord(ev[3], s));
-  hipLaunchKernelGGL(k_blur, dim3((unsigned)hp.blur_tiles.size(), n), dim3(256), 0, s, h->d_plan, h->d_tiles, h->d_pyr,
-                     h->d_blur, h->d_sel_count);
+  if (prof) SD_HIP_CHECK(hipEventRecord(ev[7], s));
+  SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_blur_done, 0));
+  if (h->wait_before_outputs) SD_HIP_CHECK(hipStreamWaitEvent(s, h->wait_before_outputs, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[4], s));
   const int cap = std::max(P.nsel, 1);
   hipLaunchKernelGGL(k_orient_desc, dim3((cap + 3) / 4, n), dim3(256), 0, s, h->d_plan, h->d_pyr, h->d_blur, h->d_sel,
@@ -941,7 +950,10 @@ int sd_orb_create(int nfeatures, float scale_factor, int nlevels, int th_fast, i
   if (e == hipSuccess) e = hipMalloc(&h->d_desc, cap * max_batch * 32);
   if (e == hipSuccess) e = hipMalloc(&h->d_nout, (size_t)max_batch * 4);
   for (int r = 0; r < sd_orb::kRing && e == hipSuccess; r++)
-    for (int i = 0; i <= ST_COUNT && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
+    for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_pyr_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_blur_done, hipEventDisableTiming);
   if (e != hipSuccess) {
     set_error(std::string("sd_orb_create: ") + hipGetErrorString(e));
     sd_orb_destroy(h);
@@ -961,8 +973,11 @@ void sd_orb_destroy(sd_orb* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (int r = 0; r < sd_orb::kRing; r++)
-    for (int i = 0; i <= ST_COUNT; i++)
+    for (int i = 0; i < 8; i++)
       if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
+  if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  if (h->ev_pyr_done) (void)hipEventDestroy(h->ev_pyr_done);
+  if (h->ev_blur_done) (void)hipEventDestroy(h->ev_blur_done);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -1162,6 +1177,7 @@ int sd_orb_set_stream(sd_orb* h, void* hip_stream) {
 int sd_orb_sync(sd_orb* h) {
   SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
   SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipStreamSynchronize(h->aux_stream));
   SD_HIP_CHECK(hipStreamSynchronize(h->stream));
   return SD_OK;
 }
@@ -1183,11 +1199,13 @@ int sd_orb_stage_ms(sd_orb* h, float* ms_out, int cap) {
   SD_HIP_CHECK(hipStreamSynchronize(h->stream));
   const int n = std::min(h->ev_calls, (int)sd_orb::kRing);
   for (int i = 0; i < ST_COUNT; i++) ms_out[i] = 0.f;
+  static const int kBegin[ST_COUNT] = {0, 1, 2, 3, 4}, kEnd[ST_COUNT] = {1, 2, 7, 6, 5};
+  SD_HIP_CHECK(hipStreamSynchronize(h->aux_stream));
   for (int r = 0; r < n; r++) {
     const int slot = (h->ev_calls - 1 - r) % sd_orb::kRing;
     for (int i = 0; i < ST_COUNT; i++) {
       float ms = 0;
-      SD_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[slot][i], h->ev[slot][i + 1]));
+      SD_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[slot][kBegin[i]], h->ev[slot][kEnd[i]]));
       ms_out[i] += ms / n;
     }
   }

@@ -16,6 +16,12 @@ struct sd_orb {
   int cur_w = 0, cur_h = 0;
   int last_frames = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  // blur depends only on the pyramid: it runs on aux_stream beside FAST + selection
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_pyr_done = nullptr, ev_blur_done = nullptr, ev_blur_start = nullptr;
+  // set by a tracker: the previous step's PnP still reads this handle's keypoints, so the kernel
+  // that overwrites them (k_orient_desc) waits for it
+  hipEvent_t wait_before_outputs = nullptr;
   // device buffers
   sd::OrbPlan* d_plan = nullptr;
   sd::CellGeom* d_cells = nullptr;
@@ -36,7 +42,8 @@ struct sd_orb {
   bool profiling = false;
   // ring of per-call stage events: the bench reads mean stage times over its whole timed region
   static const int kRing = 128;
-  hipEvent_t ev[kRing][ST_COUNT + 1] = {};
+  // per call: [0] start, [1] pyramid end, [2] FAST end, [7] select end, [3]/[6] blur start/end (aux stream), [4]/[5] descriptor start/end
+  hipEvent_t ev[kRing][8] = {};
   int ev_calls = 0;   // calls recorded since profiling was (re-)enabled
 };
 

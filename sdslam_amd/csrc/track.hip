@@ -30,6 +30,11 @@ struct sd_track {
   float* d_inv_sf = nullptr;
   float* d_sigma2 = nullptr;
   std::vector<void*> allocs;
+  // PnP is latency-bound (one wavefront per frame): it runs on its own stream so that the next
+  // batch's pyramid / FAST / selection overlap it; the kernel that overwrites the keypoints it
+  // reads (k_orient_desc of the next extraction on `cur`) waits for ev_pnp_done.
+  hipStream_t pnp_stream = nullptr;
+  hipEvent_t ev_match_done = nullptr, ev_pnp_done = nullptr;
   bool profiling = false;
   static const int kRing = 128;
   hipEvent_t ev[kRing][6] = {};
@@ -107,6 +112,9 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
     if (e == hipSuccess) e = hipMemcpy(h->d_sigma2, cur->hp.sigma2.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
     for (int r = 0; r < sd_track::kRing && e == hipSuccess; r++)
       for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->pnp_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_match_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_pnp_done, hipEventDisableTiming);
     if (e != hipSuccess) {
       set_error(std::string("sd_track_create: ") + hipGetErrorString(e));
       rc = SD_ERR_HIP;
@@ -123,7 +131,12 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
 void sd_track_destroy(sd_track* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  if (h->pnp_stream) (void)hipStreamSynchronize(h->pnp_stream);
   if (h->cur && h->cur->stream) (void)hipStreamSynchronize(h->cur->stream);
+  if (h->cur && h->cur->wait_before_outputs == h->ev_pnp_done) h->cur->wait_before_outputs = nullptr;
+  if (h->pnp_stream) (void)hipStreamDestroy(h->pnp_stream);
+  if (h->ev_match_done) (void)hipEventDestroy(h->ev_match_done);
+  if (h->ev_pnp_done) (void)hipEventDestroy(h->ev_pnp_done);
   for (void* p : h->allocs) (void)hipFree(p);
   for (int r = 0; r < sd_track::kRing; r++)
     for (int i = 0; i < 6; i++)
@@ -148,7 +161,8 @@ int sd_track_set_camera(sd_track* h, float fx, float fy, float cx, float cy, flo
 #define TRACK_RANGE(h, frame0, n)                                                                        \
   SD_REQUIRE((h), SD_ERR_INVALID_ARG, "handle is NULL");                                                 \
   SD_REQUIRE((frame0) >= 0 && (n) >= 1 && (frame0) + (n) <= (h)->max_batch, SD_ERR_CAPACITY, "frame range exceeds max_batch"); \
-  SD_HIP_CHECK(hipSetDevice((h)->device))
+  SD_HIP_CHECK(hipSetDevice((h)->device));                                                               \
+  SD_HIP_CHECK(hipStreamSynchronize((h)->pnp_stream))
 
 int sd_track_set_last(sd_track* h, int frame0, int n_frames, const int32_t* n_last, const uint8_t* valid, const double* Xw,
                       const uint8_t* desc, const int32_t* octave, const float* angle, const int32_t* obs) {
@@ -240,11 +254,15 @@ int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers,
   pp.th2 = th2;
   pp.n_iterations = n_iterations;
   pp.rand_per_frame = h->rand_per_frame;
-  hipStream_t s = h->cur->stream;
+  hipStream_t s = h->pnp_stream;
+  SD_HIP_CHECK(hipEventRecord(h->ev_match_done, h->cur->stream));   // everything queued so far (extract, align, match)
+  SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_match_done, 0));
   hipEvent_t* ev = h->ev[h->ev_calls[2] % sd_track::kRing];
   if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[4], s));
   rc = launch_pnp(h->cur, h->tb, h->cam, h->d_sigma2, pp, n_frames, s);
   if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[5], s)); h->ev_calls[2]++; }
+  SD_HIP_CHECK(hipEventRecord(h->ev_pnp_done, s));
+  h->cur->wait_before_outputs = h->ev_pnp_done;   // next k_orient_desc on `cur` overwrites what PnP reads
   return rc;
 }
 
@@ -298,6 +316,7 @@ int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double f
 int sd_track_debug_read(sd_track* h, int which, int frame, void* out, size_t bytes) {
   SD_REQUIRE(h && out && frame >= 0 && frame < h->max_batch, SD_ERR_INVALID_ARG, "bad arguments");
   SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipStreamSynchronize(h->pnp_stream));
   SD_HIP_CHECK(hipStreamSynchronize(h->cur->stream));
   const void* src = which == 0 ? (const void*)(h->tb.pnp_pts + (size_t)frame * h->kp_cap * 6)
                                : (const void*)(h->tb.pnp_kpidx + (size_t)frame * h->kp_cap);
@@ -317,6 +336,7 @@ int sd_track_stage_ms(sd_track* h, float* ms_out, int cap) {
   SD_REQUIRE(h && ms_out && cap >= 3, SD_ERR_INVALID_ARG, "bad arguments");
   SD_REQUIRE(h->profiling, SD_ERR_INVALID_ARG, "profiling is off");
   SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipStreamSynchronize(h->pnp_stream));
   SD_HIP_CHECK(hipStreamSynchronize(h->cur->stream));
   for (int k = 0; k < 3; k++) {
     ms_out[k] = 0;
