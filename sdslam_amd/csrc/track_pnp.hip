@@ -40,7 +40,7 @@ struct LArr {
 // ---- one-sided Jacobi SVD (OpenCV 3.2 JacobiSVDImpl_<double>), n <= 12 --------------------
 // Split in two: the rotation sweeps (jacobi_sweeps / jacobi_sweeps12_reg) and the common tail
 // (final norms, descending sort, normalisation / zero-singular-value fill-in).
-__device__ void jacobi_sweeps(double* At, int astep, double* W, double* Vt, int vstep, int m, int n) {
+__device__ __noinline__ void jacobi_sweeps(double* At, int astep, double* W, double* Vt, int vstep, int m, int n) {
   const double eps = DBL_EPSILON * 10;
   int i, j, k, iter, max_iter = m > 30 ? m : 30;
   double c, s, sd;
@@ -162,7 +162,7 @@ __device__ void jacobi_sweeps12_reg(Ptr At, double* W) {
 }
 
 template <typename Ptr>
-__device__ void jacobi_finish(Ptr At, int astep, double* W, double* Wout, double* Vt, int vstep, int m, int n, int n1) {
+__device__ __noinline__ void jacobi_finish(Ptr At, int astep, double* W, double* Wout, double* Vt, int vstep, int m, int n, int n1) {
   const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
   int i, j, k, iter;
   double s, sd;
@@ -231,10 +231,74 @@ __device__ void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int 
 // singular vectors (descending singular values).  A^T == A, so no transpose copy is needed; the
 // right singular vectors are not needed by EPnP and are not formed (they only ride along in
 // JacobiSVDImpl_'s final row swaps).
+// Same sweeps with the matrix left in (lane-interleaved) LDS: ~1/4 of the registers of the
+// register-resident version, so the PnP wave no longer owns a whole SIMD's register file and
+// other kernels (the next batch's pyramid / FAST) can run beside it.  Identical operation order.
+template <typename Ptr>
+__device__ __noinline__ void jacobi_sweeps12_mem(Ptr A, double* W) {
+  const double eps = DBL_EPSILON * 10;
+  for (int i = 0; i < 12; i++) {
+    double sd = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      const double t = A[i * 12 + k];
+      sd += t * t;
+    }
+    W[i] = sd;
+  }
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+    for (int i = 0; i < 11; i++)
+      for (int j = i + 1; j < 12; j++) {
+        const Ptr Ai = A + i * 12, Aj = A + j * 12;
+        double ai[12], aj[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+          ai[k] = Ai[k];
+          aj[k] = Aj[k];
+        }
+        double p = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) p += ai[k] * aj[k];
+        const double a = W[i], b = W[j];
+        if (fabs(p) <= eps * sqrt(a * b)) continue;
+        p *= 2;
+        double c, s;
+        const double beta = a - b, gamma = sdsc::hypot_glibc(p, beta);
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          s = sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        double na = 0, nb = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+          const double t0 = c * ai[k] + s * aj[k];
+          const double t1 = -s * ai[k] + c * aj[k];
+          Ai[k] = t0;
+          Aj[k] = t1;
+          na += t0 * t0;
+          nb += t1 * t1;
+        }
+        W[i] = na;
+        W[j] = nb;
+        changed = true;
+      }
+    if (!changed) break;
+  }
+}
+
 template <typename Ptr>
 __device__ void svd_sym12_inplace(Ptr A, double* Wout) {
   double W[12];
+#ifdef SD_PNP_REG_JACOBI
   jacobi_sweeps12_reg(A, W);
+#else
+  jacobi_sweeps12_mem(A, W);
+#endif
   jacobi_finish(A, 12, W, Wout, (double*)nullptr, 12, 12, 12, 12);
 }
 
@@ -365,7 +429,7 @@ struct EpnpCam { double fu, fv, uc, vc; };
 //               two of the 78 upper-triangle entries per lane, each summed over the correspondences
 //               in the reference's order (bit-identical sums), and exchanged through `lds_mtm`.
 template <bool WAVE, typename Ptr>
-__device__ double epnp_compute_pose(int n, const double* pws, const double* us, double* alphas, double* pcs,
+__device__ __noinline__ double epnp_compute_pose(int n, const double* pws, const double* us, double* alphas, double* pcs,
                                     const EpnpCam cam, double R[3][3], double t[3], Ptr ut /* 144 */, Ptr L /* 60 */,
                                     double* lds_mtm = nullptr) {
   double cws[4][3], ccs[4][3];
@@ -680,7 +744,7 @@ __device__ __forceinline__ bool pnp_is_inlier(const double* Rt, const float* q /
   return error2 < maxErr;
 }
 
-__global__ __launch_bounds__(64) void k_pnp(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all,
+__global__ __launch_bounds__(64, 4) void k_pnp(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all,
                                             TrackBuffers tb, TrackCam tcam, const float* __restrict__ sigma2, PnpParams pp) {
   // gathered correspondences live in HBM (read-mostly, L2-resident): {u, v, X, Y, Z, maxErr} f32
   __shared__ double s_work[PNP_CHUNK * (144 + 60)];   // per-lane EPnP matrices, lane-interleaved
