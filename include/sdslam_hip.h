@@ -79,6 +79,14 @@ int sd_orb_extract_batch_device(sd_orb* h, const void* d_imgs, int n_frames, int
 int sd_orb_download(sd_orb* h, int frame0, int n_frames, sd_keypoint* kps_out, uint8_t* desc_out,
                     int cap_per_frame, int32_t* n_out);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:335-366): with k1 != 0 every extraction also produces
+ * mvKeysUn = cv::undistortPoints(mvKeys, K, {k1,k2,p1,p2,k3}, R=I, P=K); the tracking stages read
+ * the undistorted keypoints.  K is the CV_32F camera matrix Converter::toCvMat builds. */
+int sd_orb_set_distortion(sd_orb* h, float fx, float fy, float cx, float cy, float k1, float k2,
+                          float p1, float p2, float k3);
+int sd_orb_download_undistorted(sd_orb* h, int frame0, int n_frames, sd_keypoint* kps_un_out,
+                                int cap_per_frame);
+
 /* std::vector<cv::Mat>& imagePyramid of operator(): level geometry and a host copy of one
  * level of one frame of the last batch (padded != 0: including the 19-px REFLECT_101 border
  * the reference keeps around each level, src/ORBextractor.cc:684-697). */
@@ -146,6 +154,14 @@ int sd_track_set_poses(sd_track* h, int frame0, int n_frames, const double* Tref
 /* raw rand() values consumed by SD_SLAM::Random, 4 per RANSAC iteration (src/extra/utils.cc:23-26,
  * src/PnPsolver.cc:185-194); rand_values is [n_frames][per_frame] */
 int sd_track_set_rand(sd_track* h, int frame0, int n_frames, const int32_t* rand_values, int per_frame);
+
+/* Stereo / RGB-D information of the current frames: either mvuRight directly, or
+ * Frame::ComputeStereoFromRGBD (src/Frame.cc:399-417) from CV_32F depth images in host memory
+ * (mvDepth, mvuRight = kpU.x - mbf / d); bf comes from sd_track_set_camera. */
+int sd_track_set_uright(sd_track* h, int frame0, int n_frames, const float* uright, int cap);
+int sd_track_stereo_from_depth(sd_track* h, int n_frames, const float* depth, int w, int hgt,
+                               int stride_elems, size_t frame_stride_elems);
+int sd_track_get_stereo(sd_track* h, int frame0, int n_frames, float* uright, float* depth, int cap);
 
 int sd_track_align(sd_track* h, int n_frames, int mode);
 int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori);

@@ -247,6 +247,17 @@ def search_by_projection(kps_un, desc, sf, bounds, K, T_cw, T_lw, last, th=8.0, 
     return n, cm
 
 
+def stereo_from_rgbd(kps, kps_un, depth, mbf):
+    """Frame::ComputeStereoFromRGBD -> (mvuRight, mvDepth)."""
+    L = lib()
+    kps, kps_un = np.ascontiguousarray(kps), np.ascontiguousarray(kps_un)
+    d = np.ascontiguousarray(depth, np.float32)
+    ur, dd = np.zeros(len(kps), np.float32), np.zeros(len(kps), np.float32)
+    L.orc_stereo_from_rgbd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_stereo_from_rgbd(len(kps), _p(kps), _p(kps_un), _p(d), d.shape[1], float(mbf), _p(ur), _p(dd))
+    return ur, dd
+
+
 def features_in_area(kps_un, bounds, x, y, r, min_level=-1, max_level=-1):
     L = lib()
     kps_un = np.ascontiguousarray(kps_un)
@@ -352,3 +363,14 @@ def glibc_rand_stream(n, seed=1):
         if i >= 344:
             out.append(v >> 1)
     return np.array(out, np.int32)
+
+
+def undistort_points(xy, K, dist5):
+    """Frame::UndistortKeyPoints / cv::undistortPoints(pts, pts, K, dist, Mat(), K)."""
+    L = lib()
+    xy = np.ascontiguousarray(xy, np.float32)
+    d = np.ascontiguousarray(dist5, np.float32)
+    out = np.zeros_like(xy)
+    L.orc_undistort_points.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_undistort_points(len(xy), _p(xy), float(K[0]), float(K[1]), float(K[2]), float(K[3]), _p(d), _p(out))
+    return out

@@ -215,6 +215,57 @@ int orc_search_by_projection(int N, const void* keysUn_, const uint8_t* desc, co
 
 int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
 
+// Frame::UndistortKeyPoints (reference src/Frame.cc:335-366): cv::undistortPoints(pts, pts, K, dist, Mat(), K)
+// restated from OpenCV 3.2 cvUndistortPoints (5 fixed-point iterations, fp64 inside, f32 in/out;
+// K arrives as the CV_32F matrix Converter::toCvMat builds; dist = {k1,k2,p1,p2,k3} floats).
+// k1 == 0 -> copy (src/Frame.cc:336-339).
+void orc_undistort_points(int n, const float* xy_in, float fxf, float fyf, float cxf, float cyf, const float* dist5, float* xy_out) {
+  if (dist5[0] == 0.0f) {
+    for (int i = 0; i < 2 * n; i++) xy_out[i] = xy_in[i];
+    return;
+  }
+  double k[12] = {dist5[0], dist5[1], dist5[2], dist5[3], dist5[4], 0, 0, 0, 0, 0, 0, 0};
+  const double fx = fxf, fy = fyf, cx = cxf, cy = cyf;
+  const double ifx = 1. / fx, ify = 1. / fy;
+  for (int i = 0; i < n; i++) {
+    double x = xy_in[2 * i], y = xy_in[2 * i + 1];
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      double r2 = x * x + y * y;
+      double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+      double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    double xx = fx * x + 0.0 * y + cx;
+    double yy = 0.0 * x + fy * y + cy;
+    double ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    xy_out[2 * i] = (float)(xx * ww);
+    xy_out[2 * i + 1] = (float)(yy * ww);
+  }
+}
+
+// Frame::ComputeStereoFromRGBD -- src/Frame.cc:399-417.  imDepth.at<float>(v, u) takes int arguments:
+// the float keypoint coordinates are truncated.  depth: CV_32F image with `stride` floats per row.
+void orc_stereo_from_rgbd(int N, const void* keys_, const void* keysUn_, const float* depth, int stride, float mbf, float* uRight,
+                          float* mvDepth) {
+  const KeyPoint* keys = (const KeyPoint*)keys_;
+  const KeyPoint* keysUn = (const KeyPoint*)keysUn_;
+  for (int i = 0; i < N; i++) {
+    uRight[i] = -1;
+    mvDepth[i] = -1;
+    const float v = keys[i].y, u = keys[i].x;
+    const float d = depth[(size_t)(int)v * stride + (int)u];
+    if (d > 0) {
+      mvDepth[i] = d;
+      uRight[i] = keysUn[i].x - mbf / d;
+    }
+  }
+}
+
 // GetFeaturesInArea exposed for known-answer tests; returns count, indices in reference order
 int orc_features_in_area(int N, const void* keysUn, float minX, float maxX, float minY, float maxY, float x, float y, float r,
                          int minLevel, int maxLevel, int* out, int cap) {

@@ -216,6 +216,17 @@ class ORBextractor:
         _check(self.L.sd_orb_download(self.h, frame0, n_frames, _p(kps), _p(desc), self.cap, _p(n)))
         return kps, desc, n
 
+    def set_distortion(self, fx, fy, cx, cy, k1, k2=0.0, p1=0.0, p2=0.0, k3=0.0):
+        """Frame::UndistortKeyPoints parameters (mK as CV_32F, mDistCoef); k1 == 0 disables."""
+        self.L.sd_orb_set_distortion.argtypes = [C.c_void_p] + [C.c_float] * 9
+        _check(self.L.sd_orb_set_distortion(self.h, fx, fy, cx, cy, k1, k2, p1, p2, k3))
+
+    def download_undistorted(self, frame0=0, n_frames=1):
+        kps = np.zeros((n_frames, self.cap), KP_DTYPE)
+        self.L.sd_orb_download_undistorted.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _check(self.L.sd_orb_download_undistorted(self.h, frame0, n_frames, _p(kps), self.cap))
+        return kps
+
     # --- pyramid / diagnostics ---
     def level_size(self, level):
         w, h = C.c_int(), C.c_int()
@@ -355,6 +366,24 @@ class Tracker:
         r = np.ascontiguousarray(rand_values, np.int32)
         assert r.ndim == 2
         _check(self.L.sd_track_set_rand(self.h, frame0, r.shape[0], _p(r), r.shape[1]))
+
+    def set_uright(self, frame0, uright):
+        u = np.ascontiguousarray(uright, np.float32)
+        self.L.sd_track_set_uright.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _check(self.L.sd_track_set_uright(self.h, frame0, u.shape[0], _p(u), u.shape[1]))
+
+    def stereo_from_depth(self, depth):
+        """Frame::ComputeStereoFromRGBD for the current frames; depth: [n, H, W] float32."""
+        d = np.ascontiguousarray(depth, np.float32)
+        self.L.sd_track_stereo_from_depth.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t]
+        _check(self.L.sd_track_stereo_from_depth(self.h, d.shape[0], _p(d), d.shape[2], d.shape[1], d.shape[2], d.shape[1] * d.shape[2]))
+
+    def get_stereo(self, frame0, n):
+        u = np.zeros((n, self.cap), np.float32)
+        d = np.zeros((n, self.cap), np.float32)
+        self.L.sd_track_get_stereo.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        _check(self.L.sd_track_get_stereo(self.h, frame0, n, _p(u), _p(d), self.cap))
+        return u, d
 
     def align(self, n_frames, mode=0):
         _check(self.L.sd_track_align(self.h, n_frames, mode))

@@ -801,6 +801,40 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_undistort: Frame::UndistortKeyPoints (src/Frame.cc:335-366) = cv::undistortPoints(pts, pts, K,
+// dist, Mat(), K), OpenCV 3.2: normalise, 5 fixed-point iterations of the radial/tangential
+// model in fp64, re-project with P = K, narrow to f32.  One thread per keypoint.
+// ------------------------------------------------------------------------------------------
+struct DistParams { double fx, fy, cx, cy, k[12]; };
+
+__global__ void k_undistort(const sd_keypoint* __restrict__ kps, sd_keypoint* __restrict__ kps_un, const int32_t* __restrict__ nout,
+                            int cap, DistParams D) {
+  const int frame = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nout[frame]) return;
+  sd_keypoint kp = kps[(size_t)frame * cap + i];
+  const double ifx = 1. / D.fx, ify = 1. / D.fy;
+  double x = kp.x, y = kp.y;
+  x = (x - D.cx) * ifx;
+  y = (y - D.cy) * ify;
+  const double x0 = x, y0 = y;
+  for (int j = 0; j < 5; j++) {
+    const double r2 = x * x + y * y;
+    const double icdist = (1 + ((D.k[7] * r2 + D.k[6]) * r2 + D.k[5]) * r2) / (1 + ((D.k[4] * r2 + D.k[1]) * r2 + D.k[0]) * r2);
+    const double deltaX = 2 * D.k[2] * x * y + D.k[3] * (r2 + 2 * x * x) + D.k[8] * r2 + D.k[9] * r2 * r2;
+    const double deltaY = D.k[2] * (r2 + 2 * y * y) + 2 * D.k[3] * x * y + D.k[10] * r2 + D.k[11] * r2 * r2;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  const double xx = D.fx * x + 0.0 * y + D.cx;
+  const double yy = 0.0 * x + D.fy * y + D.cy;
+  const double ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+  kp.x = (float)(xx * ww);
+  kp.y = (float)(yy * ww);
+  kps_un[(size_t)frame * cap + i] = kp;
+}
+
 }  // namespace sd
 
 // ==========================================================================================
@@ -897,6 +931,12 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   const int cap = std::max(P.nsel, 1);
   hipLaunchKernelGGL(k_orient_desc, dim3((cap + 3) / 4, n), dim3(256), 0, s, h->d_plan, h->d_pyr, h->d_blur, h->d_sel,
                      h->d_sel_count, h->d_kps, h->d_desc, h->d_nout, cap);
+  if (h->have_dist) {   // mvKeysUn != mvKeys only when k1 != 0 (src/Frame.cc:336-339)
+    DistParams D;
+    D.fx = h->dist_K[0]; D.fy = h->dist_K[1]; D.cx = h->dist_K[2]; D.cy = h->dist_K[3];
+    for (int i = 0; i < 12; i++) D.k[i] = i < 5 ? (double)h->dist[i] : 0.0;
+    hipLaunchKernelGGL(k_undistort, dim3((cap + 255) / 256, n), dim3(256), 0, s, h->d_kps, h->d_kps_un, h->d_nout, cap, D);
+  }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[5], s));
   SD_HIP_CHECK(hipGetLastError());
   if (prof) h->ev_calls++;
@@ -947,6 +987,7 @@ int sd_orb_create(int nfeatures, float scale_factor, int nlevels, int th_fast, i
   if (e == hipSuccess) e = hipMalloc(&h->d_plan, sizeof(OrbPlan));
   if (e == hipSuccess) e = hipMalloc(&h->d_img, (size_t)max_w * max_h * max_batch);
   if (e == hipSuccess) e = hipMalloc(&h->d_kps, cap * max_batch * sizeof(sd_keypoint));
+  if (e == hipSuccess) e = hipMalloc(&h->d_kps_un, cap * max_batch * sizeof(sd_keypoint));
   if (e == hipSuccess) e = hipMalloc(&h->d_desc, cap * max_batch * 32);
   if (e == hipSuccess) e = hipMalloc(&h->d_nout, (size_t)max_batch * 4);
   for (int r = 0; r < sd_orb::kRing && e == hipSuccess; r++)
@@ -969,7 +1010,7 @@ void sd_orb_destroy(sd_orb* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_geom(h);
-  void* ptrs[] = {h->d_plan, h->d_img, h->d_kps, h->d_desc, h->d_nout};
+  void* ptrs[] = {h->d_plan, h->d_img, h->d_kps, h->d_kps_un, h->d_desc, h->d_nout};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (int r = 0; r < sd_orb::kRing; r++)
@@ -1096,6 +1137,34 @@ int sd_orb_extract(sd_orb* h, const uint8_t* img, int w, int hgt, int stride, sd
   int rc = sd_orb_extract_batch(h, img, 1, w, hgt, stride, (size_t)stride * (hgt > 0 ? hgt : 0), kps_out, desc_out, cap, &n);
   *n_out = n;
   return rc;
+}
+
+int sd_orb_set_distortion(sd_orb* h, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2, float k3) {
+  SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  SD_REQUIRE(fx > 0 && fy > 0, SD_ERR_INVALID_ARG, "bad camera matrix");
+  h->dist_K[0] = fx; h->dist_K[1] = fy; h->dist_K[2] = cx; h->dist_K[3] = cy;
+  h->dist[0] = k1; h->dist[1] = k2; h->dist[2] = p1; h->dist[3] = p2; h->dist[4] = k3;
+  h->have_dist = (k1 != 0.0f);   // mDistCoef.at<float>(0) == 0.0 -> mvKeysUn = mvKeys
+  return SD_OK;
+}
+
+int sd_orb_download_undistorted(sd_orb* h, int frame0, int n_frames, sd_keypoint* kps_un_out, int cap_per_frame) {
+  SD_REQUIRE(h && kps_un_out, SD_ERR_INVALID_ARG, "NULL argument");
+  SD_REQUIRE(frame0 >= 0 && n_frames >= 1 && frame0 + n_frames <= h->last_frames, SD_ERR_INVALID_ARG, "frame range outside the last batch");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  const int cap = std::max(h->hp.plan.nsel, 1);
+  std::vector<int32_t> n(n_frames);
+  SD_HIP_CHECK(hipMemcpyAsync(n.data(), h->d_nout + frame0, (size_t)n_frames * 4, hipMemcpyDeviceToHost, h->stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  const sd_keypoint* src = h->have_dist ? h->d_kps_un : h->d_kps;
+  for (int f = 0; f < n_frames; f++) {
+    SD_REQUIRE(n[f] <= cap_per_frame, SD_ERR_CAPACITY, "cap_per_frame smaller than keypoint count");
+    if (n[f] > 0)
+      SD_HIP_CHECK(hipMemcpyAsync(kps_un_out + (size_t)f * cap_per_frame, src + (size_t)(frame0 + f) * cap, (size_t)n[f] * sizeof(sd_keypoint),
+                                  hipMemcpyDeviceToHost, h->stream));
+  }
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SD_OK;
 }
 
 int sd_orb_level_info(const sd_orb* h, int level, int* w, int* hgt) {

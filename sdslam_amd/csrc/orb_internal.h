@@ -36,6 +36,10 @@ struct sd_orb {
   uint32_t* d_sel = nullptr;
   int32_t* d_sel_count = nullptr;
   sd_keypoint* d_kps = nullptr;
+  sd_keypoint* d_kps_un = nullptr;   // Frame::mvKeysUn (== d_kps when k1 == 0)
+  bool have_dist = false;
+  float dist_K[4] = {0, 0, 0, 0};    // fx, fy, cx, cy as CV_32F (Converter::toCvMat)
+  float dist[5] = {0, 0, 0, 0, 0};   // k1, k2, p1, p2, k3
   uint8_t* d_desc = nullptr;
   int32_t* d_nout = nullptr;
   size_t cap_pyr = 0, cap_cand = 0, cap_cells = 0, cap_tiles = 0, cap_coef = 0;

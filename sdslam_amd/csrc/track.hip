@@ -96,6 +96,8 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.al_iters, B * 16));
   A(dalloc(h, &tb.cur_match, B * K));
   A(dalloc(h, &tb.n_matches, B));
+  A(dalloc(h, &tb.uright, B * K));
+  A(dalloc(h, &tb.depth, B * K));
   A(dalloc(h, &tb.rand_stream, B * (size_t)h->rand_per_frame));
   A(dalloc(h, &tb.pnp_T, B * 16));
   A(dalloc(h, &tb.pnp_inliers, B * K));
@@ -106,6 +108,12 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &h->d_sf, (size_t)cur->nlevels));
   A(dalloc(h, &h->d_inv_sf, (size_t)cur->nlevels));
   A(dalloc(h, &h->d_sigma2, (size_t)cur->nlevels));
+  if (rc == SD_OK) {
+    std::vector<float> neg((size_t)B * K, -1.f);
+    hipError_t e0 = hipMemcpy(tb.uright, neg.data(), neg.size() * 4, hipMemcpyHostToDevice);
+    if (e0 == hipSuccess) e0 = hipMemcpy(tb.depth, neg.data(), neg.size() * 4, hipMemcpyHostToDevice);
+    if (e0 != hipSuccess) { set_error(std::string("sd_track_create: ") + hipGetErrorString(e0)); rc = SD_ERR_HIP; }
+  }
   if (rc == SD_OK) {
     hipError_t e = hipMemcpy(h->d_sf, cur->hp.sf.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_inv_sf, cur->hp.inv_sf.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
@@ -229,13 +237,55 @@ int sd_track_align(sd_track* h, int n_frames, int mode) {
 int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori) {
   int rc = check_ready(h, n_frames);
   if (rc != SD_OK) return rc;
-  SD_REQUIRE(mono != 0, SD_ERR_INVALID_ARG, "only monocular frames are supported in this round (mvuRight == -1)");
   hipStream_t s = h->cur->stream;
   hipEvent_t* ev = h->ev[h->ev_calls[1] % sd_track::kRing];
   if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[2], s));
   rc = launch_match(h->cur, h->tb, h->cam, h->d_sf, n_frames, th, mono, check_ori, s);
   if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[3], s)); h->ev_calls[1]++; }
   return rc;
+}
+
+// CurrentFrame.mvuRight supplied by the caller (stereo) -- [n_frames][kp_cap] floats, -1 = none
+int sd_track_set_uright(sd_track* h, int frame0, int n_frames, const float* uright, int cap) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(uright && cap >= 1 && cap <= h->kp_cap, SD_ERR_INVALID_ARG, "bad uright array");
+  SD_HIP_CHECK(hipMemcpy2DAsync(h->tb.uright + (size_t)frame0 * h->kp_cap, (size_t)h->kp_cap * 4, uright, (size_t)cap * 4, (size_t)cap * 4,
+                                n_frames, hipMemcpyHostToDevice, h->cur->stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->cur->stream));
+  return SD_OK;
+}
+
+// Frame::ComputeStereoFromRGBD on the current frames of the batch: depth images (CV_32F, host memory)
+int sd_track_stereo_from_depth(sd_track* h, int n_frames, const float* depth, int w, int hgt, int stride_elems, size_t frame_stride_elems) {
+  int rc = check_ready(h, n_frames);
+  if (rc != SD_OK) return rc;
+  SD_REQUIRE(depth && w >= 1 && hgt >= 1 && stride_elems >= w, SD_ERR_INVALID_ARG, "bad depth image");
+  float* d_depth = nullptr;
+  const size_t total = (size_t)n_frames * w * hgt;
+  SD_HIP_CHECK(hipMalloc(&d_depth, total * 4));
+  hipStream_t s = h->cur->stream;
+  hipError_t e = hipSuccess;
+  for (int f = 0; f < n_frames && e == hipSuccess; f++)
+    e = hipMemcpy2DAsync(d_depth + (size_t)f * w * hgt, (size_t)w * 4, depth + (size_t)f * frame_stride_elems, (size_t)stride_elems * 4,
+                         (size_t)w * 4, hgt, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) rc = launch_stereo_from_depth(h->cur, h->tb, h->cam, d_depth, w, hgt, w, (size_t)w * hgt, n_frames, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(d_depth);
+  if (e != hipSuccess || e2 != hipSuccess) {
+    set_error(std::string("sd_track_stereo_from_depth: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return SD_ERR_HIP;
+  }
+  return rc;
+}
+
+int sd_track_get_stereo(sd_track* h, int frame0, int n_frames, float* uright, float* depth, int cap) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(cap >= h->kp_cap, SD_ERR_CAPACITY, "cap smaller than the keypoint capacity");
+  hipStream_t s = h->cur->stream;
+  if (uright) SD_HIP_CHECK(hipMemcpy2DAsync(uright, (size_t)cap * 4, h->tb.uright + (size_t)frame0 * h->kp_cap, (size_t)h->kp_cap * 4, (size_t)h->kp_cap * 4, n_frames, hipMemcpyDeviceToHost, s));
+  if (depth) SD_HIP_CHECK(hipMemcpy2DAsync(depth, (size_t)cap * 4, h->tb.depth + (size_t)frame0 * h->kp_cap, (size_t)h->kp_cap * 4, (size_t)h->kp_cap * 4, n_frames, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
 }
 
 int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers, int max_iterations, int min_set, float epsilon,

@@ -31,6 +31,8 @@ struct TrackBuffers {
   // SearchByProjection outputs
   int32_t* cur_match;    // [B][kp_cap]  index into the last-frame arrays or -1
   int32_t* n_matches;    // [B]
+  float* uright;         // [B][kp_cap]  CurrentFrame.mvuRight (-1: no stereo/depth information)
+  float* depth;          // [B][kp_cap]  CurrentFrame.mvDepth
   // PnP
   int32_t* rand_stream;  // [B][4*pnp_max_its] raw rand() values
   float* pnp_T;          // [B][16] row-major CV_32F 4x4
@@ -60,6 +62,8 @@ int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, c
                  const float* d_sf, int n_frames, int mode, hipStream_t s);
 int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, int n_frames, float th,
                  int mono, int check_ori, hipStream_t s);
+int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_depth, int w, int h,
+                             int stride_elems, size_t frame_stride_elems, int n_frames, hipStream_t s);
 int launch_pnp(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sigma2, const PnpParams& pp,
                int n_frames, hipStream_t s);
 

@@ -14,8 +14,9 @@
 // with Observations() > 0 is skipped by later ones; otherwise later points overwrite), so one
 // wavefront walks the last frame's points in order and parallelises each point's window:
 // lanes take candidates, compute Hamming distances, and a wave-min over (dist, order, index)
-// yields the reference's "first strict minimum".  Monocular frames only in this round
-// (mvuRight = -1, bForward = bBackward = false); keypoints are assumed undistorted (k1 == 0).
+// yields the reference's "first strict minimum".  Stereo / RGB-D gates (mvuRight, bForward /
+// bBackward octave windows) follow src/ORBmatcher.cc:965-966,999-1004,1020-1025; keypoints are
+// the undistorted ones (Frame::mvKeysUn).
 #include <hip/hip_runtime.h>
 
 #include "orb_internal.h"
@@ -103,6 +104,17 @@ __global__ __launch_bounds__(256) void k_match(const sd_keypoint* __restrict__ k
   }
   int nmatches = 0, nev = 0;
   const float factor = 1.0f / HISTO_LENGTH;
+  const float* uright = tb.uright + (size_t)f * cap;
+  // bForward / bBackward: tlc = Rlw * (-Rcw^T tcw) + tlw compared with the baseline mb
+  bool bForward = false, bBackward = false;
+  if (!mono) {
+    const double* Tl = tb.Tref + (size_t)f * 16;
+    double twc[3], tlc2;
+    for (int i = 0; i < 3; i++) twc[i] = (-R[0][i]) * t[0] + (-R[1][i]) * t[1] + (-R[2][i]) * t[2];
+    tlc2 = (Tl[0 * 4 + 2] * twc[0] + Tl[1 * 4 + 2] * twc[1] + Tl[2 * 4 + 2] * twc[2]) + Tl[12 + 2];
+    bForward = tlc2 > cam.mb;
+    bBackward = -tlc2 > cam.mb;
+  }
 
   for (int i = 0; i < n_last; i++) {
     if (!valid[i]) continue;
@@ -119,7 +131,8 @@ __global__ __launch_bounds__(256) void k_match(const sd_keypoint* __restrict__ k
     if (v < cam.min_y || v > cam.max_y) continue;
     const int nLastOctave = l_oct[i];
     const float radius = th * sf[nLastOctave];
-    const int minLevel = nLastOctave - 1, maxLevel = nLastOctave + 1;   // mono: neither forward nor backward
+    const int minLevel = bForward ? nLastOctave : (bBackward ? 0 : nLastOctave - 1);
+    const int maxLevel = bForward ? -1 : (bBackward ? nLastOctave : nLastOctave + 1);
     // GetFeaturesInArea(u, v, radius, minLevel, maxLevel)
     const int nMinCellX = max(0, (int)floorf((u - cam.min_x - radius) * invW));
     if (nMinCellX >= GRID_COLS) continue;
@@ -151,6 +164,12 @@ __global__ __launch_bounds__(256) void k_match(const sd_keypoint* __restrict__ k
           if (okc) {
             const int m = s_match[idx];
             bool claimed = (m >= 0) && (l_obs[m] > 0);
+            const float ur2 = uright[idx];
+            if (!claimed && ur2 > 0) {   // stereo consistency gate (src/ORBmatcher.cc:1020-1025)
+              const float ur = u - cam.bf * invzc;
+              const float er = fabsf(ur - ur2);
+              if (er > radius) claimed = true;
+            }
             if (!claimed) {
               const unsigned long long* dk = (const unsigned long long*)(desc + (size_t)idx * 32);
               const int dist = __popcll(dk[0] ^ d0) + __popcll(dk[1] ^ d1) + __popcll(dk[2] ^ d2) + __popcll(dk[3] ^ d3);
@@ -222,9 +241,40 @@ __global__ __launch_bounds__(256) void k_match(const sd_keypoint* __restrict__ k
   if (lane == 0) tb.n_matches[f] = nmatches;
 }
 
+// Frame::ComputeStereoFromRGBD (src/Frame.cc:399-417): d = imDepth.at<float>(kp.pt.y, kp.pt.x) at the
+// DISTORTED keypoint (coordinates truncated to int); mvDepth = d, mvuRight = kpU.pt.x - mbf / d if d > 0.
+__global__ void k_stereo_from_depth(const sd_keypoint* __restrict__ kps, const sd_keypoint* __restrict__ kps_un,
+                                    const int32_t* __restrict__ nkp, TrackBuffers tb, TrackCam cam, const float* __restrict__ depth,
+                                    int w, int h, int stride, size_t frame_stride) {
+  const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x, cap = tb.kp_cap;
+  if (i >= cap) return;
+  float ur = -1.f, dd = -1.f;
+  if (i < nkp[f]) {
+    const sd_keypoint kp = kps[(size_t)f * cap + i];
+    const int v = (int)kp.y, u = (int)kp.x;
+    if (u >= 0 && v >= 0 && u < w && v < h) {
+      const float d = depth[(size_t)f * frame_stride + (size_t)v * stride + u];
+      if (d > 0) {
+        dd = d;
+        ur = kps_un[(size_t)f * cap + i].x - cam.bf / d;
+      }
+    }
+  }
+  tb.uright[(size_t)f * cap + i] = ur;
+  tb.depth[(size_t)f * cap + i] = dd;
+}
+
+int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_depth, int w, int h,
+                             int stride_elems, size_t frame_stride_elems, int n_frames, hipStream_t s) {
+  hipLaunchKernelGGL(k_stereo_from_depth, dim3((tb.kp_cap + 255) / 256, n_frames), dim3(256), 0, s, cur->d_kps,
+                     (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam, d_depth, w, h, stride_elems, frame_stride_elems);
+  SD_HIP_CHECK(hipGetLastError());
+  return SD_OK;
+}
+
 int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, int n_frames, float th,
                  int mono, int check_ori, hipStream_t s) {
-  hipLaunchKernelGGL(k_match, dim3(n_frames), dim3(256), 0, s, cur->d_kps, cur->d_desc, cur->d_nout, tb, cam, d_sf, th, mono,
+  hipLaunchKernelGGL(k_match, dim3(n_frames), dim3(256), 0, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_desc, cur->d_nout, tb, cam, d_sf, th, mono,
                      check_ori);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;

@@ -1004,7 +1004,7 @@ int run_epnp_debug(int n, const double* Xw, const double* uv, double fx, double 
 
 int launch_pnp(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sigma2, const PnpParams& pp,
                int n_frames, hipStream_t s) {
-  hipLaunchKernelGGL(k_pnp, dim3(n_frames), dim3(64), 0, s, cur->d_kps, cur->d_nout, tb, cam, d_sigma2, pp);
+  hipLaunchKernelGGL(k_pnp, dim3(n_frames), dim3(64), 0, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam, d_sigma2, pp);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }

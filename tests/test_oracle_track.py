@@ -210,3 +210,38 @@ def test_pnp_too_few_points(oracle):
     assert p.params()["N"] == 20
     r = p.iterate(50, oracle.glibc_rand_stream(800))
     assert r["ok"] and not r["inliers"][::2].any() and r["inliers"][1::2].all()
+
+
+def test_undistort_points_kat(oracle):
+    """cvUndistortPoints restatement: forward-distorting a grid with the Brown model and undistorting it
+    returns the grid (5 fixed-point iterations: a few 1e-3 px inside, 0.05 px in the corners at TUM1 distortion); k1 == 0 copies."""
+    Kd = (517.3, 516.5, 318.6, 255.3)
+    dist = np.array([0.2624, -0.9531, -0.0054, 0.0026, 1.1633])
+    gx, gy = np.meshgrid(np.linspace(20, 620, 25), np.linspace(20, 460, 19))
+    x, y = (gx.ravel() - Kd[2]) / Kd[0], (gy.ravel() - Kd[3]) / Kd[1]
+    r2 = x * x + y * y
+    cd = 1 + dist[0] * r2 + dist[1] * r2 ** 2 + dist[4] * r2 ** 3
+    xd = x * cd + 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x)
+    yd = y * cd + dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y
+    pix = np.stack([xd * Kd[0] + Kd[2], yd * Kd[1] + Kd[3]], 1).astype(np.float32)
+    out = oracle.undistort_points(pix, Kd, dist)
+    err = np.abs(out - np.stack([gx.ravel(), gy.ravel()], 1)).max(1)
+    assert err[r2 < 0.2].max() < 5e-3 and err.max() < 0.1      # 5 iterations: corners converge less
+    d0 = dist.copy()
+    d0[0] = 0
+    assert np.array_equal(oracle.undistort_points(pix, Kd, d0), pix)
+
+
+def test_stereo_from_rgbd_kat(oracle):
+    """Frame::ComputeStereoFromRGBD: depth read at the truncated distorted coordinates, uRight from the
+    undistorted x; d <= 0 leaves -1."""
+    from oracle.oracle import KP_DTYPE
+    k = np.zeros(4, KP_DTYPE)
+    ku = np.zeros(4, KP_DTYPE)
+    k["x"], k["y"] = [10.9, 20.2, 5.0, 7.99], [3.7, 4.0, 6.5, 8.01]
+    ku["x"] = [11.5, 20.0, 5.25, 8.0]
+    depth = np.zeros((12, 32), np.float32)
+    depth[3, 10], depth[4, 20], depth[6, 5], depth[8, 7] = 2.0, 0.0, -1.0, 0.5
+    ur, dd = oracle.stereo_from_rgbd(k, ku, depth, 40.0)
+    assert np.array_equal(dd, np.float32([2.0, -1, -1, 0.5]))
+    assert np.array_equal(ur, np.float32([np.float32(11.5) - np.float32(40) / np.float32(2), -1, -1, np.float32(8.0) - np.float32(80.0)]))

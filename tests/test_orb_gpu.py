@@ -109,3 +109,29 @@ def test_errors_are_loud(sd):
     with pytest.raises(sd.SdError):
         ext.extract_batch(np.zeros((2, 480, 640), np.uint8))   # exceeds max_batch
     ext.close()
+
+
+def test_undistort_keypoints_bit_exact(sd, oracle):
+    """Frame::UndistortKeyPoints (src/Frame.cc:333-363): mvKeysUn for a TUM1-like camera vs the oracle's
+    cvUndistortPoints restatement; k1 == 0 -> mvKeysUn == mvKeys."""
+    Kd = (517.3, 516.5, 318.6, 255.3)
+    dist = (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)
+    imgs = np.stack([make_image(70 + i) for i in range(2)])
+    ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2)
+    ext.set_distortion(*Kd, *dist)
+    kps, desc, n = ext.extract_batch(imgs)
+    un = ext.download_undistorted(0, 2)
+    for i in range(2):
+        k = kps[i, :n[i]]
+        xy = np.stack([k["x"], k["y"]], 1)
+        ref = oracle.undistort_points(xy, Kd, dist)
+        u = un[i, :n[i]]
+        assert np.array_equal(u["x"], ref[:, 0]) and np.array_equal(u["y"], ref[:, 1])
+        assert np.abs(ref - xy).max() > 0.5                       # the distortion is not a no-op
+        for fld in ("size", "angle", "response", "octave"):
+            assert np.array_equal(u[fld], k[fld])
+    ext.set_distortion(*Kd, 0.0, -0.9531, -0.0054, 0.0026, 1.1633)   # k1 == 0: copy
+    kps2, _, n2 = ext.extract_batch(imgs)
+    un2 = ext.download_undistorted(0, 2)
+    for i in range(2):
+        assert np.array_equal(un2[i, :n2[i]], kps2[i, :n2[i]])

@@ -136,6 +136,54 @@ def test_match_overwrite_and_claim_semantics(sd, oracle, rig):
     trk.set_last(0, [o["last"] for o in rig["oras"]])     # restore
 
 
+def test_rgbd_stereo_gates_bit_exact(sd, oracle, rig):
+    """RGB-D frames: ComputeStereoFromRGBD (mvuRight/mvDepth) and the bForward / bBackward / uRight gates of
+    SearchByProjection (src/ORBmatcher.cc:965-966,999-1004,1020-1025).  bf = 4 (baseline 7.7 mm) so that the
+    rig's centimetre motions land on both sides of the mb threshold."""
+    trk, B = rig["trk"], rig["B"]
+    bf = 4.0
+    mb = np.float32(bf) / np.float32(K[0])
+    yy, xx = np.mgrid[0:480, 0:640].astype(np.float32)
+    depth = np.stack([(1.5 + 0.8 * np.sin(xx * 0.013 + i) * np.cos(yy * 0.017)).astype(np.float32) for i in range(B)])
+    depth[:, 100:140, :] = 0.0            # holes: no depth -> mvuRight = -1
+    depth[:, :, 300:310] = -1.0
+    try:
+        trk.set_camera(*K, bf, BOUNDS)
+        trk.stereo_from_depth(depth)
+        ur, dd = trk.get_stereo(0, B)
+        ours = []
+        for i in range(B):
+            o = rig["oras"][i]
+            our, odd = oracle.stereo_from_rgbd(o["ck"], o["ck"], depth[i], bf)
+            n = len(our)
+            assert np.array_equal(ur[i, :n], our) and np.array_equal(dd[i, :n], odd)
+            assert (ur[i, n:] == -1).all() and (our == -1).any() and (our > 0).any()
+            ours.append(our)
+        seen = set()
+        for th, scale in [(15.0, 1.0), (7.0, 1.0), (15.0, 0.0)]:
+            # scale 0: current pose == last pose -> neither forward nor backward
+            T = [s["T_cur"] if scale else s["T_ref"] for s in rig["scenes"]]
+            trk.set_poses(0, [s["T_ref"] for s in rig["scenes"]], T)
+            trk.match(B, th=th, mono=False, check_ori=True)
+            cm, nm = trk.get_matches(0, B)
+            for i in range(B):
+                o = rig["oras"][i]
+                Tl = rig["scenes"][i]["T_ref"]
+                twc = -T[i][:3, :3].T @ T[i][:3, 3]
+                tlc = Tl[:3, :3] @ twc + Tl[:3, 3]
+                seen.add("f" if tlc[2] > mb else ("b" if -tlc[2] > mb else "n"))
+                n, ocm = oracle.search_by_projection(o["ck"], o["cd"], o["tab"]["sf"], BOUNDS, K, T[i], Tl, o["last"], th=th,
+                                                     mono=False, check_ori=True, u_right=ours[i], mbf=bf, mb=mb)
+                assert nm[i] == n, (th, i, nm[i], n)
+                assert np.array_equal(cm[i, :len(ocm)], ocm)
+                # and the gate matters: the monocular result differs somewhere in the batch
+        assert seen == {"f", "b", "n"}, seen
+    finally:
+        trk.set_camera(*K, 0.0, BOUNDS)
+        trk.set_uright(0, np.full((B, 8), -1, np.float32))
+        trk.stereo_from_depth(np.zeros((B, 480, 640), np.float32))   # resets every mvuRight to -1
+
+
 def test_pnp_ransac_matches_oracle(sd, oracle, rig):
     trk, B = rig["trk"], rig["B"]
     T = [s["T_cur"] for s in rig["scenes"]]
