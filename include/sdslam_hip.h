@@ -183,6 +183,8 @@ int sd_track_get_pnp(sd_track* h, int frame0, int n_frames, float* Tcw_rowmajor,
                      int cap, int32_t* info8);
 /* diagnostics: device EPnP (PnPsolver::compute_pose, src/PnPsolver.cc:445-492) on n explicit
  * correspondences; R9 row-major, returns the mean reprojection error in *reproj_err */
+/* Stage cycle counters of k_pnp (only in a library built with -DSD_PNP_PROF; tools/prof_pnp.py) */
+int sd_debug_pnp_prof(unsigned long long* out32, int reset);
 int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy,
                   double* R9, double* t3, double* reproj_err);
 int sd_track_debug_read(sd_track* h, int which, int frame, void* out, size_t bytes);

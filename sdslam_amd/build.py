@@ -33,7 +33,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         t = os.path.getmtime(OUT)
         if all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d)):
             return OUT
-    cmd = [HIPCC] + FLAGS + ["-x", "hip"] + src + ["-o", OUT]
+    cmd = [HIPCC] + FLAGS + os.environ.get("SD_EXTRA_FLAGS", "").split() + ["-x", "hip"] + src + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

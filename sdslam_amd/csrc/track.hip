@@ -356,6 +356,11 @@ int sd_track_get_pnp(sd_track* h, int frame0, int n_frames, float* Tcw_rowmajor,
 }
 
 // EPnP (compute_pose, src/PnPsolver.cc:445-492) alone on explicit correspondences -- parity diagnostics
+int sd_debug_pnp_prof(unsigned long long* out32, int reset) {
+  SD_REQUIRE(out32, SD_ERR_INVALID_ARG, "null output");
+  return read_pnp_prof(out32, reset);
+}
+
 int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy, double* R9, double* t3,
                   double* reproj_err) {
   SD_REQUIRE(n >= 4 && Xw && uv && R9 && t3, SD_ERR_INVALID_ARG, "bad arguments");

@@ -24,109 +24,187 @@
 namespace sd {
 
 #define PNP_MAXN 1024
-#define PNP_CHUNK 16   // RANSAC hypotheses evaluated side by side (typical runs accept within the first few)
+#define PNP_CHUNK 8    // RANSAC hypotheses evaluated side by side (typical runs accept within the first few);
+                       // 3 lanes per hypothesis (one per EPnP beta variant)
 #define PNP_WORDS (PNP_MAXN / 64)
 
 // Lane-interleaved LDS array: element i of this lane lives at p[i * PNP_CHUNK], so the
 // PNP_CHUNK lanes that solve hypotheses side by side hit distinct banks.  The big per-lane EPnP
 // work arrays (12x12 Gram / singular-vector matrix, L_6x10) live here instead of in private
 // (scratch) memory: with 9 KB of scratch per lane the kernel was bound by scratch traffic.
+// Optional stage timers (build with -DSD_PNP_PROF; read through sd_debug_pnp_prof): shader-clock
+// cycles of lane 0 per stage, summed over frames.  Slots 0-8: EPnP stages of the RANSAC minimal
+// sets, 16-24: of the refit, 10-15: k_pnp phases.
+#ifdef SD_PNP_PROF
+__device__ unsigned long long g_pnp_prof[32];
+#define PROF_DECL long long _pt = clock64()
+#define PROF(i)                                                                                       \
+  do {                                                                                                \
+    long long _n = clock64();                                                                         \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_pnp_prof[i], (unsigned long long)(_n - _pt));           \
+    _pt = _n;                                                                                         \
+  } while (0)
+#else
+#define PROF_DECL
+#define PROF(i)
+#endif
+
+// LDS pointers keep their address space (ds_read / ds_write); through a generic double* every access
+// becomes a flat_load that waits on both the LDS and the global counters.
+typedef __attribute__((address_space(3))) double ldsd;
+#define LDS_PTR(shared_array) ((ldsd*)(shared_array))
 struct LArr {
-  double* p;
-  __device__ __forceinline__ double& operator[](int i) const { return p[i * PNP_CHUNK]; }
+  ldsd* p;
+  __device__ __forceinline__ ldsd& operator[](int i) const { return p[i * PNP_CHUNK]; }
   __device__ __forceinline__ LArr operator+(int off) const { return LArr{p + off * PNP_CHUNK}; }
 };
 
 // ---- one-sided Jacobi SVD (OpenCV 3.2 JacobiSVDImpl_<double>), n <= 12 --------------------
-// Split in two: the rotation sweeps (jacobi_sweeps / jacobi_sweeps12_reg) and the common tail
-// (final norms, descending sort, normalisation / zero-singular-value fill-in).
-__device__ __noinline__ void jacobi_sweeps(double* At, int astep, double* W, double* Vt, int vstep, int m, int n) {
-  const double eps = DBL_EPSILON * 10;
-  int i, j, k, iter, max_iter = m > 30 ? m : 30;
-  double c, s, sd;
+// The 12 x 12 case (EPnP's M^T M) keeps the matrix and the squared norms W in lane-interleaved LDS
+// (rotation sweeps: jacobi_sweeps12_mem; tail: jacobi_finish12); the small cases are unrolled into
+// registers (jacobi_svd_small).  Nothing lives in private memory: a dependent scratch access costs
+// a global-memory round trip, which dominated the first version of this kernel.
+// Tail of JacobiSVDImpl_ for the 12 x 12 case (final norms, descending selection sort of the rows,
+// normalisation / zero-singular-value fill-in), matrix and W in (lane-interleaved) LDS.
+template <typename Ptr>
+__device__ __noinline__ void jacobi_finish12(Ptr At, Ptr W) {
+  const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+  constexpr int m = 12, n = 12;
+  int i, j, k, iter;
+  double s, sd;
   for (i = 0; i < n; i++) {
-    for (k = 0, sd = 0; k < m; k++) {
-      double t = At[i * astep + k];
+    sd = 0;
+#pragma unroll
+    for (k = 0; k < m; k++) {
+      double t = At[i * m + k];
       sd += t * t;
     }
-    W[i] = sd;
-    for (k = 0; k < n; k++) Vt[i * vstep + k] = 0;
-    Vt[i * vstep + i] = 1;
+    W[i] = sqrt(sd);
   }
-  for (iter = 0; iter < max_iter; iter++) {
-    bool changed = false;
-    for (i = 0; i < n - 1; i++)
-      for (j = i + 1; j < n; j++) {
-        double *Ai = At + i * astep, *Aj = At + j * astep;
-        double a = W[i], p = 0, b = W[j];
-        for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
-        if (fabs(p) <= eps * sqrt(a * b)) continue;
-        p *= 2;
-        double beta = a - b, gamma = sdsc::hypot_glibc(p, beta);
-        if (beta < 0) {
-          double delta = (gamma - beta) * 0.5;
-          s = sqrt(delta / gamma);
-          c = p / (gamma * s * 2);
-        } else {
-          c = sqrt((gamma + beta) / (gamma * 2));
-          s = p / (gamma * c * 2);
-        }
-        a = b = 0;
-        for (k = 0; k < m; k++) {
-          double t0 = c * Ai[k] + s * Aj[k];
-          double t1 = -s * Ai[k] + c * Aj[k];
-          Ai[k] = t0;
-          Aj[k] = t1;
-          a += t0 * t0;
-          b += t1 * t1;
-        }
-        W[i] = a;
-        W[j] = b;
-        changed = true;
-        double *Vi = Vt + i * vstep, *Vj = Vt + j * vstep;
-        for (k = 0; k < n; k++) {
-          double t0 = c * Vi[k] + s * Vj[k];
-          double t1 = -s * Vi[k] + c * Vj[k];
-          Vi[k] = t0;
-          Vj[k] = t1;
+  for (i = 0; i < n - 1; i++) {
+    j = i;
+    double wj = W[i];
+    for (k = i + 1; k < n; k++) {
+      const double wk = W[k];
+      if (wj < wk) {
+        j = k;
+        wj = wk;
+      }
+    }
+    if (i != j) {
+      double tw = W[i]; W[i] = W[j]; W[j] = tw;
+#pragma unroll
+      for (k = 0; k < m; k++) { double t = At[i * m + k]; At[i * m + k] = At[j * m + k]; At[j * m + k] = t; }
+    }
+  }
+  unsigned long long rng = 0x12345678ull;
+  for (i = 0; i < n; i++) {
+    sd = W[i];
+    for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+      const double val0 = 1. / m;
+      for (k = 0; k < m; k++) {
+        rng = (unsigned long long)(unsigned)rng * 4164903690U + (unsigned)(rng >> 32);
+        double val = ((unsigned)rng & 256) != 0 ? val0 : -val0;
+        At[i * m + k] = val;
+      }
+      for (iter = 0; iter < 2; iter++) {
+        for (j = 0; j < i; j++) {
+          sd = 0;
+#pragma unroll
+          for (k = 0; k < m; k++) sd += At[i * m + k] * At[j * m + k];
+          double asum = 0;
+#pragma unroll
+          for (k = 0; k < m; k++) {
+            double t = At[i * m + k] - sd * At[j * m + k];
+            At[i * m + k] = t;
+            asum += fabs(t);
+          }
+          asum = asum > eps * 100 ? 1 / asum : 0;
+#pragma unroll
+          for (k = 0; k < m; k++) At[i * m + k] *= asum;
         }
       }
-    if (!changed) break;
+      sd = 0;
+#pragma unroll
+      for (k = 0; k < m; k++) {
+        double t = At[i * m + k];
+        sd += t * t;
+      }
+      sd = sqrt(sd);
+    }
+    s = sd > minval ? 1 / sd : 0.;
+#pragma unroll
+    for (k = 0; k < m; k++) At[i * m + k] *= s;
   }
 }
 
-// The 12x12 case (EPnP's M^T M, evaluated per RANSAC hypothesis) with the matrix held in
-// REGISTERS: all (i, j, k) loops are unrolled so every index is a compile-time constant; the
-// operation sequence is exactly jacobi_sweeps' (same sums in the same order), only the storage
-// differs.  The right singular vectors are not needed by any 12x12 caller, so Vt is left as the
-// identity (it only rides along in the tail's row swaps).
-template <typename Ptr>
-__device__ void jacobi_sweeps12_reg(Ptr At, double* W) {
-  const double eps = DBL_EPSILON * 10;
-  double a[12][12], w[12];
+// Zero-singular-value fill-in of row i (JacobiSVDImpl_'s tail): rare, so it stays generic and
+// works on a private-memory copy.  Returns the row's new norm.
+__device__ __noinline__ double jacobi_fill_row(double* At, int astep, int m, int i, unsigned long long* rng_io, double sd) {
+  const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+  unsigned long long rng = *rng_io;
+  for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+    const double val0 = 1. / m;
+    for (int k = 0; k < m; k++) {
+      rng = (unsigned long long)(unsigned)rng * 4164903690U + (unsigned)(rng >> 32);
+      double val = ((unsigned)rng & 256) != 0 ? val0 : -val0;
+      At[i * astep + k] = val;
+    }
+    for (int iter = 0; iter < 2; iter++) {
+      for (int j = 0; j < i; j++) {
+        sd = 0;
+        for (int k = 0; k < m; k++) sd += At[i * astep + k] * At[j * astep + k];
+        double asum = 0;
+        for (int k = 0; k < m; k++) {
+          double t = At[i * astep + k] - sd * At[j * astep + k];
+          At[i * astep + k] = t;
+          asum += fabs(t);
+        }
+        asum = asum > eps * 100 ? 1 / asum : 0;
+        for (int k = 0; k < m; k++) At[i * astep + k] *= asum;
+      }
+    }
+    sd = 0;
+    for (int k = 0; k < m; k++) {
+      double t = At[i * astep + k];
+      sd += t * t;
+    }
+    sd = sqrt(sd);
+  }
+  *rng_io = rng;
+  return sd;
+}
+
+// The small SVDs of EPnP (3 x 3, and 6 x {3,4,5} inside cvSolve) with compile-time shapes: every
+// loop is unrolled so the matrices live in REGISTERS (the generic version keeps them in private
+// memory, where each dependent access costs a scratch round trip).  Same operation order as
+// jacobi_sweeps + jacobi_finish; At = N rows of length M (the transposed input), Vt = N x N.
+template <int M, int N>
+__device__ __forceinline__ void jacobi_svd_small(double (&At)[N][M], double (&Wout)[N], double (&Vt)[N][N]) {
+  const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+  double W[N];
 #pragma unroll
-  for (int i = 0; i < 12; i++) {
+  for (int i = 0; i < N; i++) {
     double sd = 0;
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
-      a[i][k] = At[i * 12 + k];
-      sd += a[i][k] * a[i][k];
-    }
-    w[i] = sd;
+    for (int k = 0; k < M; k++) sd += At[i][k] * At[i][k];
+    W[i] = sd;
+#pragma unroll
+    for (int k = 0; k < N; k++) Vt[i][k] = k == i ? 1 : 0;
   }
-  for (int iter = 0; iter < 30; iter++) {
+  for (int iter = 0; iter < 30; iter++) {   // max_iter = max(m, 30)
     bool changed = false;
 #pragma unroll
-    for (int i = 0; i < 11; i++) {
+    for (int i = 0; i < N - 1; i++) {
 #pragma unroll
-      for (int j = i + 1; j < 12; j++) {
+      for (int j = i + 1; j < N; j++) {
         double p = 0;
 #pragma unroll
-        for (int k = 0; k < 12; k++) p += a[i][k] * a[j][k];
-        if (!(fabs(p) <= eps * sqrt(w[i] * w[j]))) {
+        for (int k = 0; k < M; k++) p += At[i][k] * At[j][k];
+        if (!(fabs(p) <= eps * sqrt(W[i] * W[j]))) {
           p *= 2;
           double c, s;
-          const double beta = w[i] - w[j], gamma = sdsc::hypot_glibc(p, beta);
+          const double beta = W[i] - W[j], gamma = sdsc::hypot_glibc(p, beta);
           if (beta < 0) {
             const double delta = (gamma - beta) * 0.5;
             s = sqrt(delta / gamma);
@@ -137,105 +215,83 @@ __device__ void jacobi_sweeps12_reg(Ptr At, double* W) {
           }
           double na = 0, nb = 0;
 #pragma unroll
-          for (int k = 0; k < 12; k++) {
-            const double t0 = c * a[i][k] + s * a[j][k];
-            const double t1 = -s * a[i][k] + c * a[j][k];
-            a[i][k] = t0;
-            a[j][k] = t1;
+          for (int k = 0; k < M; k++) {
+            const double t0 = c * At[i][k] + s * At[j][k];
+            const double t1 = -s * At[i][k] + c * At[j][k];
+            At[i][k] = t0;
+            At[j][k] = t1;
             na += t0 * t0;
             nb += t1 * t1;
           }
-          w[i] = na;
-          w[j] = nb;
+          W[i] = na;
+          W[j] = nb;
           changed = true;
+#pragma unroll
+          for (int k = 0; k < N; k++) {
+            const double t0 = c * Vt[i][k] + s * Vt[j][k];
+            const double t1 = -s * Vt[i][k] + c * Vt[j][k];
+            Vt[i][k] = t0;
+            Vt[j][k] = t1;
+          }
         }
       }
     }
     if (!changed) break;
   }
 #pragma unroll
-  for (int i = 0; i < 12; i++) {
-    W[i] = w[i];
+  for (int i = 0; i < N; i++) {
+    double sd = 0;
 #pragma unroll
-    for (int k = 0; k < 12; k++) At[i * 12 + k] = a[i][k];
-  }
-}
-
-template <typename Ptr>
-__device__ __noinline__ void jacobi_finish(Ptr At, int astep, double* W, double* Wout, double* Vt, int vstep, int m, int n, int n1) {
-  const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
-  int i, j, k, iter;
-  double s, sd;
-  for (i = 0; i < n; i++) {
-    for (k = 0, sd = 0; k < m; k++) {
-      double t = At[i * astep + k];
-      sd += t * t;
-    }
+    for (int k = 0; k < M; k++) sd += At[i][k] * At[i][k];
     W[i] = sqrt(sd);
   }
-  for (i = 0; i < n - 1; i++) {
-    j = i;
-    for (k = i + 1; k < n; k++)
-      if (W[j] < W[k]) j = k;
-    if (i != j) {
-      double tw = W[i]; W[i] = W[j]; W[j] = tw;
-      for (k = 0; k < m; k++) { double t = At[i * astep + k]; At[i * astep + k] = At[j * astep + k]; At[j * astep + k] = t; }
-      if (Vt)
-        for (k = 0; k < n; k++) { double t = Vt[i * vstep + k]; Vt[i * vstep + k] = Vt[j * vstep + k]; Vt[j * vstep + k] = t; }
-    }
+#pragma unroll
+  for (int i = 0; i < N - 1; i++) {   // selection sort, descending
+    int j = i;
+    double wj = W[i];
+#pragma unroll
+    for (int k = i + 1; k < N; k++)
+      if (wj < W[k]) {
+        j = k;
+        wj = W[k];
+      }
+#pragma unroll
+    for (int jj = i + 1; jj < N; jj++)
+      if (jj == j) {
+        const double tw = W[i]; W[i] = W[jj]; W[jj] = tw;
+#pragma unroll
+        for (int k = 0; k < M; k++) { const double t = At[i][k]; At[i][k] = At[jj][k]; At[jj][k] = t; }
+#pragma unroll
+        for (int k = 0; k < N; k++) { const double t = Vt[i][k]; Vt[i][k] = Vt[jj][k]; Vt[jj][k] = t; }
+      }
   }
-  for (i = 0; i < n; i++) Wout[i] = W[i];
+#pragma unroll
+  for (int i = 0; i < N; i++) Wout[i] = W[i];
   unsigned long long rng = 0x12345678ull;
-  for (i = 0; i < n1; i++) {
-    sd = i < n ? W[i] : 0;
-    for (int ii = 0; ii < 100 && sd <= minval; ii++) {
-      const double val0 = 1. / m;
-      for (k = 0; k < m; k++) {
-        rng = (unsigned long long)(unsigned)rng * 4164903690U + (unsigned)(rng >> 32);
-        double val = ((unsigned)rng & 256) != 0 ? val0 : -val0;
-        At[i * astep + k] = val;
-      }
-      for (iter = 0; iter < 2; iter++) {
-        for (j = 0; j < i; j++) {
-          sd = 0;
-          for (k = 0; k < m; k++) sd += At[i * astep + k] * At[j * astep + k];
-          double asum = 0;
-          for (k = 0; k < m; k++) {
-            double t = At[i * astep + k] - sd * At[j * astep + k];
-            At[i * astep + k] = t;
-            asum += fabs(t);
-          }
-          asum = asum > eps * 100 ? 1 / asum : 0;
-          for (k = 0; k < m; k++) At[i * astep + k] *= asum;
-        }
-      }
-      sd = 0;
-      for (k = 0; k < m; k++) {
-        double t = At[i * astep + k];
-        sd += t * t;
-      }
-      sd = sqrt(sd);
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double sd = W[i];
+    if (sd <= minval) {   // vanished singular value: build an orthogonal row (generic path on a copy)
+      double tmp[N * M];
+      for (int r = 0; r < N; r++)
+        for (int k = 0; k < M; k++) tmp[r * M + k] = At[r][k];
+      sd = jacobi_fill_row(tmp, M, M, i, &rng, sd);
+#pragma unroll
+      for (int k = 0; k < M; k++) At[i][k] = tmp[i * M + k];
     }
-    s = sd > minval ? 1 / sd : 0.;
-    for (k = 0; k < m; k++) At[i * astep + k] *= s;
+    const double s = sd > minval ? 1 / sd : 0.;
+#pragma unroll
+    for (int k = 0; k < M; k++) At[i][k] *= s;
   }
-}
-
-__device__ void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int vstep, int m, int n, int n1) {
-  double W[12];
-  jacobi_sweeps(At, astep, W, Vt, vstep, m, n);
-  jacobi_finish(At, astep, W, Wout, Vt, vstep, m, n, n1);
 }
 
 // cvSVD of the symmetric 12x12 M^T M held (in place) in `A`: on return rows of A are the left
 // singular vectors (descending singular values).  A^T == A, so no transpose copy is needed; the
 // right singular vectors are not needed by EPnP and are not formed (they only ride along in
 // JacobiSVDImpl_'s final row swaps).
-// Same sweeps with the matrix left in (lane-interleaved) LDS: ~1/4 of the registers of the
-// register-resident version, so the PnP wave no longer owns a whole SIMD's register file and
-// other kernels (the next batch's pyramid / FAST) can run beside it.  Identical operation order.
+// Rotation sweeps; rows are copied to registers per (i, j) pair, everything else stays in LDS.
 template <typename Ptr>
-__device__ __noinline__ void jacobi_sweeps12_mem(Ptr A, double* W) {
+__device__ __noinline__ void jacobi_sweeps12_mem(Ptr A, Ptr W) {
   const double eps = DBL_EPSILON * 10;
   for (int i = 0; i < 12; i++) {
     double sd = 0;
@@ -292,47 +348,65 @@ __device__ __noinline__ void jacobi_sweeps12_mem(Ptr A, double* W) {
 }
 
 template <typename Ptr>
-__device__ void svd_sym12_inplace(Ptr A, double* Wout) {
-  double W[12];
-#ifdef SD_PNP_REG_JACOBI
-  jacobi_sweeps12_reg(A, W);
-#else
-  jacobi_sweeps12_mem(A, W);
-#endif
-  jacobi_finish(A, 12, W, Wout, (double*)nullptr, 12, 12, 12, 12);
+__device__ void svd_sym12_inplace(Ptr A /* 144 matrix + 12 squared norms */) {
+  jacobi_sweeps12_mem(A, A + 144);
+  jacobi_finish12(A, A + 144);
 }
 
-// SVD of a square row-major n x n matrix (n = 3 or 12): Ut rows = left vectors, Vt rows = right
-__device__ void svd_square(const double* A, int n, double* W, double* Ut, double* Vt) {
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < n; j++) Ut[i * n + j] = A[j * n + i];
-  jacobi_svd(Ut, n, W, Vt, n, n, n, n);
+// cvSVD of a row-major 3 x 3 matrix: Ut rows = left vectors, Vt rows = right vectors
+__device__ __noinline__ void svd3(const double* A, double* W, double* Ut, double* Vt) {
+  double at[3][3], w[3], vt[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) at[i][j] = A[j * 3 + i];
+  jacobi_svd_small<3, 3>(at, w, vt);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    W[i] = w[i];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      Ut[i * 3 + j] = at[i][j];
+      Vt[i * 3 + j] = vt[i][j];
+    }
+  }
 }
 
-// cvSolve(A (6 x n), b, x, CV_SVD)
-__device__ void solve_svd6(const double* A, int n, const double* b, double* x) {
-  double a[30], v[25], w[5];
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < 6; j++) a[i * 6 + j] = A[j * n + i];
-  jacobi_svd(a, 6, w, v, n, 6, n, n);
-  for (int i = 0; i < n; i++) x[i] = 0;
+// cvSolve(A (6 x N), b, x, CV_SVD); A row-major with row stride N
+template <int N>
+__device__ __noinline__ void solve_svd6(const double* A, const double* b, double* x) {
+  double a[N][6], v[N][N], w[N];
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) a[i][j] = A[j * N + i];
+  jacobi_svd_small<6, N>(a, w, v);
+  double xr[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) xr[i] = 0;
   double threshold = 0;
-  for (int i = 0; i < n; i++) threshold += w[i];
+#pragma unroll
+  for (int i = 0; i < N; i++) threshold += w[i];
   threshold *= DBL_EPSILON * 2;
-  for (int i = 0; i < n; i++) {
+#pragma unroll
+  for (int i = 0; i < N; i++) {
     double wi = w[i];
     if (fabs(wi) <= threshold) continue;
     wi = 1 / wi;
     double s = 0;
-    for (int j = 0; j < 6; j++) s += a[i * 6 + j] * b[j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) s += a[i][j] * b[j];
     s *= wi;
-    for (int j = 0; j < n; j++) x[j] = x[j] + s * v[i * n + j];
+#pragma unroll
+    for (int j = 0; j < N; j++) xr[j] = xr[j] + s * v[i][j];
   }
+#pragma unroll
+  for (int i = 0; i < N; i++) x[i] = xr[i];
 }
 
 __device__ void invert_svd3(const double* A, double* Ainv) {
   double w[3], ut[9], vt[9];
-  svd_square(A, 3, w, ut, vt);
+  svd3(A, w, ut, vt);
   for (int i = 0; i < 9; i++) Ainv[i] = 0;
   double threshold = (w[0] + w[1] + w[2]) * DBL_EPSILON * 2;
   for (int i = 0; i < 3; i++) {
@@ -351,187 +425,109 @@ __device__ __forceinline__ double dist2_3(const double* p1, const double* p2) {
   return (p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]) + (p1[2] - p2[2]) * (p1[2] - p2[2]);
 }
 
-__device__ void qr_solve64(double* pA, double* pb, double* pX) {   // 6 x 4 Householder QR (src/PnPsolver.cc:812-901)
-  const int nr = 6, nc = 4;
-  double A1[4], A2[4];
-  double* ppAkk = pA;
+// 6 x 4 Householder QR solve (src/PnPsolver.cc:812-901) with every index a compile-time constant
+// (registers).  NB the reference's pivot search reads rows k .. nr-2 (it re-reads A[k][k] and never
+// looks at the last row); that is kept.  A is row-major 6 x 4.
+__device__ __noinline__ void qr_solve64(double* pA, double* pb, double* pX) {
+  constexpr int nr = 6, nc = 4;
+  double A[nr][nc], b[nr], A1[nc], A2[nc];
+#pragma unroll
+  for (int i = 0; i < nr; i++) {
+    b[i] = pb[i];
+#pragma unroll
+    for (int j = 0; j < nc; j++) A[i][j] = pA[i * nc + j];
+  }
+  bool singular = false;
+#pragma unroll
   for (int k = 0; k < nc; k++) {
-    double *ppAik = ppAkk, eta = fabs(*ppAik);
+    if (singular) break;
+    double eta = fabs(A[k][k]);
+#pragma unroll
     for (int i = k + 1; i < nr; i++) {
-      double elt = fabs(*ppAik);
+      const double elt = fabs(A[i - 1][k]);
       if (eta < elt) eta = elt;
-      ppAik += nc;
     }
     if (eta == 0) {
-      A1[k] = A2[k] = 0.0;
-      return;
+      singular = true;   // "God damnit, A is singular, this shouldn't happen." -- x is left untouched
     } else {
-      double *q = ppAkk, sum = 0.0, inv_eta = 1. / eta;
+      double sum = 0.0;
+      const double inv_eta = 1. / eta;
+#pragma unroll
       for (int i = k; i < nr; i++) {
-        *q *= inv_eta;
-        sum += *q * *q;
-        q += nc;
+        A[i][k] *= inv_eta;
+        sum += A[i][k] * A[i][k];
       }
       double sigma = sqrt(sum);
-      if (*ppAkk < 0) sigma = -sigma;
-      *ppAkk += sigma;
-      A1[k] = sigma * *ppAkk;
+      if (A[k][k] < 0) sigma = -sigma;
+      A[k][k] += sigma;
+      A1[k] = sigma * A[k][k];
       A2[k] = -eta * sigma;
+#pragma unroll
       for (int j = k + 1; j < nc; j++) {
-        double *q2 = ppAkk, sum2 = 0;
-        for (int i = k; i < nr; i++) {
-          sum2 += *q2 * q2[j - k];
-          q2 += nc;
-        }
-        double tau = sum2 / A1[k];
-        q2 = ppAkk;
-        for (int i = k; i < nr; i++) {
-          q2[j - k] -= tau * *q2;
-          q2 += nc;
-        }
+        double sum2 = 0;
+#pragma unroll
+        for (int i = k; i < nr; i++) sum2 += A[i][k] * A[i][j];
+        const double tau = sum2 / A1[k];
+#pragma unroll
+        for (int i = k; i < nr; i++) A[i][j] -= tau * A[i][k];
       }
     }
-    ppAkk += nc + 1;
   }
-  double* ppAjj = pA;
+  if (singular) return;
+#pragma unroll
   for (int j = 0; j < nc; j++) {
-    double *ppAij = ppAjj, tau = 0;
-    for (int i = j; i < nr; i++) {
-      tau += *ppAij * pb[i];
-      ppAij += nc;
-    }
+    double tau = 0;
+#pragma unroll
+    for (int i = j; i < nr; i++) tau += A[i][j] * b[i];
     tau /= A1[j];
-    ppAij = ppAjj;
-    for (int i = j; i < nr; i++) {
-      pb[i] -= tau * *ppAij;
-      ppAij += nc;
-    }
-    ppAjj += nc + 1;
+#pragma unroll
+    for (int i = j; i < nr; i++) b[i] -= tau * A[i][j];
   }
-  pX[nc - 1] = pb[nc - 1] / A2[nc - 1];
+  double X[nc];
+  X[nc - 1] = b[nc - 1] / A2[nc - 1];
+#pragma unroll
   for (int i = nc - 2; i >= 0; i--) {
-    double *ppAij = pA + i * nc + (i + 1), sum = 0;
-    for (int j = i + 1; j < nc; j++) {
-      sum += *ppAij * pX[j];
-      ppAij++;
-    }
-    pX[i] = (pb[i] - sum) / A2[i];
+    double sum = 0;
+#pragma unroll
+    for (int j = i + 1; j < nc; j++) sum += A[i][j] * X[j];
+    X[i] = (b[i] - sum) / A2[i];
   }
+#pragma unroll
+  for (int i = 0; i < nc; i++) pX[i] = X[i];
 }
 
 struct EpnpCam { double fu, fv, uc, vc; };
 
-// EPnP on n correspondences held in pws (3n) / us (2n); alphas (4n), pcs (3n) are work arrays.
-// WAVE = false: every lane solves its own problem (RANSAC minimal sets).
-// WAVE = true : all 64 lanes of the wave call with IDENTICAL arguments (the refit over the best
-//               inlier set): the sequential parts run redundantly (same cost as one lane), the
-//               M^T M accumulation -- the only O(n * 144) part -- is spread over the lanes, one or
-//               two of the 78 upper-triangle entries per lane, each summed over the correspondences
-//               in the reference's order (bit-identical sums), and exchanged through `lds_mtm`.
-template <bool WAVE, typename Ptr>
-__device__ __noinline__ double epnp_compute_pose(int n, const double* pws, const double* us, double* alphas, double* pcs,
-                                    const EpnpCam cam, double R[3][3], double t[3], Ptr ut /* 144 */, Ptr L /* 60 */,
-                                    double* lds_mtm = nullptr) {
-  double cws[4][3], ccs[4][3];
-  // In WAVE mode only lane 0 runs the sequential parts (63 idle lanes issue no private-memory
-  // traffic); every lane joins the barriers and the M^T M accumulation.
-  const bool lead = !WAVE || (threadIdx.x & 63) == 0;
-  if (lead) {
-  // choose_control_points
-  cws[0][0] = cws[0][1] = cws[0][2] = 0;
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < 3; j++) cws[0][j] += pws[3 * i + j];
-  for (int j = 0; j < 3; j++) cws[0][j] /= n;
-  {
-    double pw0tpw0[9], dc[3], uct[9], vtmp[9];
-    for (int a = 0; a < 3; a++)
-      for (int b = a; b < 3; b++) {
-        double s = 0;
-        for (int k = 0; k < n; k++) s += (pws[3 * k + a] - cws[0][a]) * (pws[3 * k + b] - cws[0][b]);
-        pw0tpw0[a * 3 + b] = s;
-      }
-    for (int a = 0; a < 3; a++)
-      for (int b = 0; b < a; b++) pw0tpw0[a * 3 + b] = pw0tpw0[b * 3 + a];
-    svd_square(pw0tpw0, 3, dc, uct, vtmp);
-    for (int i = 1; i < 4; i++) {
-      double k = sqrt(dc[i - 1] / n);
-      for (int j = 0; j < 3; j++) cws[i][j] = cws[0][j] + k * uct[3 * (i - 1) + j];
-    }
+// ---- EPnP building blocks (src/PnPsolver.cc:348-901), shared by the minimal-set and the refit solvers ----
+
+// choose_control_points tail: control points 1..3 from the centred covariance (pw0tpw0, full 3x3)
+__device__ void epnp_control_points(const double* pw0tpw0, int n, double cws[4][3]) {
+  double dc[3], uct[9], vtmp[9];
+  svd3(pw0tpw0, dc, uct, vtmp);
+  for (int i = 1; i < 4; i++) {
+    double k = sqrt(dc[i - 1] / n);
+    for (int j = 0; j < 3; j++) cws[i][j] = cws[0][j] + k * uct[3 * (i - 1) + j];
   }
-  // compute_barycentric_coordinates
-  {
-    double cc[9], ci[9];
-    for (int i = 0; i < 3; i++)
-      for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = cws[j][i] - cws[0][i];
-    invert_svd3(cc, ci);
-    for (int i = 0; i < n; i++) {
-      const double* pi = pws + 3 * i;
-      double* a = alphas + 4 * i;
-      for (int j = 0; j < 3; j++)
-        a[1 + j] = ci[3 * j] * (pi[0] - cws[0][0]) + ci[3 * j + 1] * (pi[1] - cws[0][1]) + ci[3 * j + 2] * (pi[2] - cws[0][2]);
-      a[0] = 1.0f - a[1] - a[2] - a[3];
-    }
-  }
-  }  // lead
-  // M^T M accumulated row by row (rows 2i, 2i+1 of M; same k-order as cvMulTransposed), built
-  // in place in `ut` (it is symmetric, so it equals the transposed copy cvSVD would make)
-  double d[12];
-  if (WAVE) {
-    const int lane = threadIdx.x & 63;
-    __syncthreads();   // alphas[] (written by the lead lane) visible; lds_mtm free
-    for (int e = lane; e < 78; e += 64) {
-      int a = 0, rem = e;
-      while (rem >= 12 - a) { rem -= 12 - a; a++; }
-      const int b = a + rem;
-      const int ka = a / 3, ca = a - 3 * ka, kb = b / 3, cb = b - 3 * kb;
-      double acc = 0;
-      for (int i = 0; i < n; i++) {
-        const double aa = alphas[4 * i + ka], ab = alphas[4 * i + kb];
-        const double u = us[2 * i], v = us[2 * i + 1];
-        const double m1a = ca == 0 ? aa * cam.fu : (ca == 1 ? 0.0 : aa * (cam.uc - u));
-        const double m1b = cb == 0 ? ab * cam.fu : (cb == 1 ? 0.0 : ab * (cam.uc - u));
-        const double m2a = ca == 0 ? 0.0 : (ca == 1 ? aa * cam.fv : aa * (cam.vc - v));
-        const double m2b = cb == 0 ? 0.0 : (cb == 1 ? ab * cam.fv : ab * (cam.vc - v));
-        acc += m1a * m1b;
-        acc += m2a * m2b;
-      }
-      lds_mtm[a * 12 + b] = acc;
-      lds_mtm[b * 12 + a] = acc;
-    }
-    __syncthreads();
-    if (lead)
-      for (int i = 0; i < 144; i++) ut[i] = lds_mtm[i];
-  } else {
-    for (int i = 0; i < 144; i++) ut[i] = 0;
-    for (int i = 0; i < n; i++) {
-      const double* as = alphas + 4 * i;
-      const double u = us[2 * i], v = us[2 * i + 1];
-      double M1[12], M2[12];
-      for (int k = 0; k < 4; k++) {
-        M1[3 * k] = as[k] * cam.fu;
-        M1[3 * k + 1] = 0.0;
-        M1[3 * k + 2] = as[k] * (cam.uc - u);
-        M2[3 * k] = 0.0;
-        M2[3 * k + 1] = as[k] * cam.fv;
-        M2[3 * k + 2] = as[k] * (cam.vc - v);
-      }
-      for (int a = 0; a < 12; a++)
-        for (int b = a; b < 12; b++) {
-          double acc = ut[a * 12 + b];
-          acc += M1[a] * M1[b];
-          acc += M2[a] * M2[b];
-          ut[a * 12 + b] = acc;
-        }
-    }
-    for (int a = 0; a < 12; a++)
-      for (int b = 0; b < a; b++) ut[a * 12 + b] = ut[b * 12 + a];
-  }
-  double bestR[3][3], bestT[3], best_err = 0;
-  if (lead) {
-  svd_sym12_inplace(ut, d);
-  // compute_L_6x10 / compute_rho
-  double rho[6];
-  {
+}
+
+// compute_barycentric_coordinates: CC^-1 (cvInvert, CV_SVD)
+__device__ void epnp_cc_inverse(const double cws[4][3], double ci[9]) {
+  double cc[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = cws[j][i] - cws[0][i];
+  invert_svd3(cc, ci);
+}
+
+__device__ __forceinline__ void epnp_alphas(const double* pi, const double cws[4][3], const double* ci, double* a) {
+  for (int j = 0; j < 3; j++)
+    a[1 + j] = ci[3 * j] * (pi[0] - cws[0][0]) + ci[3 * j + 1] * (pi[1] - cws[0][1]) + ci[3 * j + 2] * (pi[2] - cws[0][2]);
+  a[0] = 1.0f - a[1] - a[2] - a[3];
+}
+
+// compute_L_6x10 / compute_rho from the four null-space rows of ut
+template <typename Ptr>
+__device__ void epnp_L_rho(Ptr ut, const double cws[4][3], Ptr L, double rho[6], bool write_L) {
+  if (write_L) {
     const Ptr v4[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
     double dv[4][6][3];
     for (int i = 0; i < 4; i++) {
@@ -560,157 +556,430 @@ __device__ __noinline__ double epnp_compute_pose(int n, const double* pws, const
       row[8] = 2.0f * dot3(dv[2][i], dv[3][i]);
       row[9] = dot3(dv[3][i], dv[3][i]);
     }
-    rho[0] = dist2_3(cws[0], cws[1]);
-    rho[1] = dist2_3(cws[0], cws[2]);
-    rho[2] = dist2_3(cws[0], cws[3]);
-    rho[3] = dist2_3(cws[1], cws[2]);
-    rho[4] = dist2_3(cws[1], cws[3]);
-    rho[5] = dist2_3(cws[2], cws[3]);
   }
-  for (int variant = 1; variant <= 3; variant++) {
-    double betas[4];
-    if (variant == 1) {
-      double l[24], b4[4];
-      for (int i = 0; i < 6; i++) {
-        l[4 * i] = L[10 * i];
-        l[4 * i + 1] = L[10 * i + 1];
-        l[4 * i + 2] = L[10 * i + 3];
-        l[4 * i + 3] = L[10 * i + 6];
-      }
-      solve_svd6(l, 4, rho, b4);
-      if (b4[0] < 0) {
-        betas[0] = sqrt(-b4[0]);
-        betas[1] = -b4[1] / betas[0];
-        betas[2] = -b4[2] / betas[0];
-        betas[3] = -b4[3] / betas[0];
-      } else {
-        betas[0] = sqrt(b4[0]);
-        betas[1] = b4[1] / betas[0];
-        betas[2] = b4[2] / betas[0];
-        betas[3] = b4[3] / betas[0];
-      }
-    } else if (variant == 2) {
-      double l[18], b3[3];
-      for (int i = 0; i < 6; i++) {
-        l[3 * i] = L[10 * i];
-        l[3 * i + 1] = L[10 * i + 1];
-        l[3 * i + 2] = L[10 * i + 2];
-      }
-      solve_svd6(l, 3, rho, b3);
-      if (b3[0] < 0) {
-        betas[0] = sqrt(-b3[0]);
-        betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0;
-      } else {
-        betas[0] = sqrt(b3[0]);
-        betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0;
-      }
-      if (b3[1] < 0) betas[0] = -betas[0];
-      betas[2] = 0.0;
-      betas[3] = 0.0;
+  rho[0] = dist2_3(cws[0], cws[1]);
+  rho[1] = dist2_3(cws[0], cws[2]);
+  rho[2] = dist2_3(cws[0], cws[3]);
+  rho[3] = dist2_3(cws[1], cws[2]);
+  rho[4] = dist2_3(cws[1], cws[3]);
+  rho[5] = dist2_3(cws[2], cws[3]);
+}
+
+// find_betas_approx_{1,2,3} followed by gauss_newton (5 iterations).  The three variants depend
+// only on L and rho, never on each other, so they run on three lanes side by side.
+template <typename Ptr>
+__device__ __noinline__ void epnp_betas(int variant, Ptr L, const double* rho, double betas[4]) {
+  if (variant == 1) {
+    double l[24], b4[4];
+    for (int i = 0; i < 6; i++) {
+      l[4 * i] = L[10 * i];
+      l[4 * i + 1] = L[10 * i + 1];
+      l[4 * i + 2] = L[10 * i + 3];
+      l[4 * i + 3] = L[10 * i + 6];
+    }
+    solve_svd6<4>(l, rho, b4);
+    if (b4[0] < 0) {
+      betas[0] = sqrt(-b4[0]);
+      betas[1] = -b4[1] / betas[0];
+      betas[2] = -b4[2] / betas[0];
+      betas[3] = -b4[3] / betas[0];
     } else {
-      double l[30], b5[5];
-      for (int i = 0; i < 6; i++)
-        for (int j = 0; j < 5; j++) l[5 * i + j] = L[10 * i + j];
-      solve_svd6(l, 5, rho, b5);
-      if (b5[0] < 0) {
-        betas[0] = sqrt(-b5[0]);
-        betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0;
-      } else {
-        betas[0] = sqrt(b5[0]);
-        betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0;
+      betas[0] = sqrt(b4[0]);
+      betas[1] = b4[1] / betas[0];
+      betas[2] = b4[2] / betas[0];
+      betas[3] = b4[3] / betas[0];
+    }
+  } else if (variant == 2) {
+    double l[18], b3[3];
+    for (int i = 0; i < 6; i++) {
+      l[3 * i] = L[10 * i];
+      l[3 * i + 1] = L[10 * i + 1];
+      l[3 * i + 2] = L[10 * i + 2];
+    }
+    solve_svd6<3>(l, rho, b3);
+    if (b3[0] < 0) {
+      betas[0] = sqrt(-b3[0]);
+      betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0;
+    } else {
+      betas[0] = sqrt(b3[0]);
+      betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0;
+    }
+    if (b3[1] < 0) betas[0] = -betas[0];
+    betas[2] = 0.0;
+    betas[3] = 0.0;
+  } else {
+    double l[30], b5[5];
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 5; j++) l[5 * i + j] = L[10 * i + j];
+    solve_svd6<5>(l, rho, b5);
+    if (b5[0] < 0) {
+      betas[0] = sqrt(-b5[0]);
+      betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0;
+    } else {
+      betas[0] = sqrt(b5[0]);
+      betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0;
+    }
+    if (b5[1] < 0) betas[0] = -betas[0];
+    betas[2] = b5[3] / betas[0];
+    betas[3] = 0.0;
+  }
+  for (int k = 0; k < 5; k++) {
+    double a[24], b[6], x[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 6; i++) {
+      const Ptr rowL = L + i * 10;
+      double* rowA = a + i * 4;
+      rowA[0] = 2 * rowL[0] * betas[0] + rowL[1] * betas[1] + rowL[3] * betas[2] + rowL[6] * betas[3];
+      rowA[1] = rowL[1] * betas[0] + 2 * rowL[2] * betas[1] + rowL[4] * betas[2] + rowL[7] * betas[3];
+      rowA[2] = rowL[3] * betas[0] + rowL[4] * betas[1] + 2 * rowL[5] * betas[2] + rowL[8] * betas[3];
+      rowA[3] = rowL[6] * betas[0] + rowL[7] * betas[1] + rowL[8] * betas[2] + 2 * rowL[9] * betas[3];
+      b[i] = rho[i] - (rowL[0] * betas[0] * betas[0] + rowL[1] * betas[0] * betas[1] + rowL[2] * betas[1] * betas[1] +
+                       rowL[3] * betas[0] * betas[2] + rowL[4] * betas[1] * betas[2] + rowL[5] * betas[2] * betas[2] +
+                       rowL[6] * betas[0] * betas[3] + rowL[7] * betas[1] * betas[3] + rowL[8] * betas[2] * betas[3] +
+                       rowL[9] * betas[3] * betas[3]);
+    }
+    qr_solve64(a, b, x);
+    for (int i = 0; i < 4; i++) betas[i] += x[i];
+  }
+}
+
+// compute_ccs
+template <typename Ptr>
+__device__ __forceinline__ void epnp_ccs(Ptr ut, const double* betas, double ccs[4][3]) {
+  for (int i = 0; i < 4; i++) ccs[i][0] = ccs[i][1] = ccs[i][2] = 0.0f;
+  for (int i = 0; i < 4; i++) {
+    const Ptr v = ut + 12 * (11 - i);
+    for (int j = 0; j < 4; j++)
+      for (int k = 0; k < 3; k++) ccs[j][k] += betas[i] * v[3 * j + k];
+  }
+}
+
+// estimate_R_and_t tail: ABt -> R, t (Arun), given the centroids
+__device__ void epnp_Rt_from_abt(const double* abt, const double* pc0, const double* pw0, double Rv[3][3], double tv[3]) {
+  double abt_d[3], u3[9], v3[9];
+  svd3(abt, abt_d, u3, v3);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Rv[i][j] = u3[i] * v3[j] + u3[3 + i] * v3[3 + j] + u3[6 + i] * v3[6 + j];
+  const double det = Rv[0][0] * Rv[1][1] * Rv[2][2] + Rv[0][1] * Rv[1][2] * Rv[2][0] + Rv[0][2] * Rv[1][0] * Rv[2][1] -
+                     Rv[0][2] * Rv[1][1] * Rv[2][0] - Rv[0][1] * Rv[1][0] * Rv[2][2] - Rv[0][0] * Rv[1][2] * Rv[2][1];
+  if (det < 0) {
+    Rv[2][0] = -Rv[2][0];
+    Rv[2][1] = -Rv[2][1];
+    Rv[2][2] = -Rv[2][2];
+  }
+  tv[0] = pc0[0] - dot3(Rv[0], pw0);
+  tv[1] = pc0[1] - dot3(Rv[1], pw0);
+  tv[2] = pc0[2] - dot3(Rv[2], pw0);
+}
+
+__device__ __forceinline__ double epnp_reproj_term(const double Rv[3][3], const double tv[3], const double* pw, double u, double v,
+                                                   const EpnpCam cam) {
+  double Xc = dot3(Rv[0], pw) + tv[0];
+  double Yc = dot3(Rv[1], pw) + tv[1];
+  double inv_Zc = 1.0 / (dot3(Rv[2], pw) + tv[2]);
+  double ue = cam.uc + cam.fu * Xc * inv_Zc;
+  double ve = cam.vc + cam.fv * Yc * inv_Zc;
+  return sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+}
+
+// ---- EPnP on a RANSAC minimal set (n = 4) -------------------------------------------------------
+// Called by ALL 64 lanes.  Lane layout: hypothesis h = lane % PNP_CHUNK, beta variant = lane /
+// PNP_CHUNK + 1 (lanes >= 3 * PNP_CHUNK idle).  The three lanes of a hypothesis compute the cheap
+// front part redundantly (lock-step, so it costs nothing), the variant-1 lane alone runs the
+// 12 x 12 SVD and writes L into the hypothesis' LDS view, then each lane follows its own
+// find_betas variant / Gauss-Newton / R,t / reprojection error.  Returns that variant's error.
+template <typename Ptr>
+__device__ __noinline__ double epnp_minimal(bool active, int variant, const double* pws, const double* us, const EpnpCam cam,
+                                            double Rv[3][3], double tv[3], Ptr ut, Ptr L) {
+  constexpr int n = 4;
+  double cws[4][3], alphas[16], rho[6];
+  PROF_DECL;
+  if (active) {
+    cws[0][0] = cws[0][1] = cws[0][2] = 0;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < 3; j++) cws[0][j] += pws[3 * i + j];
+    for (int j = 0; j < 3; j++) cws[0][j] /= n;
+    double pw0tpw0[9], ci[9];
+    for (int a = 0; a < 3; a++)
+      for (int b = a; b < 3; b++) {
+        double s = 0;
+        for (int k = 0; k < n; k++) s += (pws[3 * k + a] - cws[0][a]) * (pws[3 * k + b] - cws[0][b]);
+        pw0tpw0[a * 3 + b] = s;
       }
-      if (b5[1] < 0) betas[0] = -betas[0];
-      betas[2] = b5[3] / betas[0];
-      betas[3] = 0.0;
-    }
-    // gauss_newton (5 iterations)
-    for (int k = 0; k < 5; k++) {
-      double a[24], b[6], x[4] = {0, 0, 0, 0};
-      for (int i = 0; i < 6; i++) {
-        const Ptr rowL = L + i * 10;
-        double* rowA = a + i * 4;
-        rowA[0] = 2 * rowL[0] * betas[0] + rowL[1] * betas[1] + rowL[3] * betas[2] + rowL[6] * betas[3];
-        rowA[1] = rowL[1] * betas[0] + 2 * rowL[2] * betas[1] + rowL[4] * betas[2] + rowL[7] * betas[3];
-        rowA[2] = rowL[3] * betas[0] + rowL[4] * betas[1] + 2 * rowL[5] * betas[2] + rowL[8] * betas[3];
-        rowA[3] = rowL[6] * betas[0] + rowL[7] * betas[1] + rowL[8] * betas[2] + 2 * rowL[9] * betas[3];
-        b[i] = rho[i] - (rowL[0] * betas[0] * betas[0] + rowL[1] * betas[0] * betas[1] + rowL[2] * betas[1] * betas[1] +
-                         rowL[3] * betas[0] * betas[2] + rowL[4] * betas[1] * betas[2] + rowL[5] * betas[2] * betas[2] +
-                         rowL[6] * betas[0] * betas[3] + rowL[7] * betas[1] * betas[3] + rowL[8] * betas[2] * betas[3] +
-                         rowL[9] * betas[3] * betas[3]);
-      }
-      qr_solve64(a, b, x);
-      for (int i = 0; i < 4; i++) betas[i] += x[i];
-    }
-    // compute_R_and_t: ccs, pcs, sign, Horn/Arun alignment, reprojection error
-    for (int i = 0; i < 4; i++) ccs[i][0] = ccs[i][1] = ccs[i][2] = 0.0f;
-    for (int i = 0; i < 4; i++) {
-      const Ptr v = ut + 12 * (11 - i);
-      for (int j = 0; j < 4; j++)
-        for (int k = 0; k < 3; k++) ccs[j][k] += betas[i] * v[3 * j + k];
-    }
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < a; b++) pw0tpw0[a * 3 + b] = pw0tpw0[b * 3 + a];
+    epnp_control_points(pw0tpw0, n, cws);
+    PROF(0);
+    epnp_cc_inverse(cws, ci);
+    for (int i = 0; i < n; i++) epnp_alphas(pws + 3 * i, cws, ci, alphas + 4 * i);
+    PROF(1);
+  }
+  if (active && variant == 1) {
+    // M^T M accumulated row by row (rows 2i, 2i+1 of M; same k-order as cvMulTransposed), built in
+    // place in `ut` (symmetric, so it equals the transposed copy cvSVD would make)
+    for (int i = 0; i < 144; i++) ut[i] = 0;
     for (int i = 0; i < n; i++) {
+      const double* as = alphas + 4 * i;
+      const double u = us[2 * i], v = us[2 * i + 1];
+      double M1[12], M2[12];
+      for (int k = 0; k < 4; k++) {
+        M1[3 * k] = as[k] * cam.fu;
+        M1[3 * k + 1] = 0.0;
+        M1[3 * k + 2] = as[k] * (cam.uc - u);
+        M2[3 * k] = 0.0;
+        M2[3 * k + 1] = as[k] * cam.fv;
+        M2[3 * k + 2] = as[k] * (cam.vc - v);
+      }
+      for (int a = 0; a < 12; a++)
+        for (int b = a; b < 12; b++) {
+          double acc = ut[a * 12 + b];
+          acc += M1[a] * M1[b];
+          acc += M2[a] * M2[b];
+          ut[a * 12 + b] = acc;
+        }
+    }
+    for (int a = 0; a < 12; a++)
+      for (int b = 0; b < a; b++) ut[a * 12 + b] = ut[b * 12 + a];
+    PROF(2);
+    svd_sym12_inplace(ut);
+    PROF(3);
+  }
+  epnp_L_rho(ut, cws, L, rho, active && variant == 1);
+  PROF(4);
+  __syncthreads();   // ut / L of every hypothesis visible to its variant lanes
+  double err = 0;
+  if (active) {
+    double betas[4], ccs[4][3], pcs[12];
+    epnp_betas(variant, L, rho, betas);
+    PROF(6);
+    epnp_ccs(ut, betas, ccs);
+    for (int i = 0; i < n; i++) {
+      const double* a = alphas + 4 * i;
+      for (int j = 0; j < 3; j++) pcs[3 * i + j] = a[0] * ccs[0][j] + a[1] * ccs[1][j] + a[2] * ccs[2][j] + a[3] * ccs[3][j];
+    }
+    if (pcs[2] < 0.0)   // solve_for_sign (the sign of ccs is not used afterwards)
+      for (int i = 0; i < 3 * n; i++) pcs[i] = -pcs[i];
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < 3; j++) {
+        pc0[j] += pcs[3 * i + j];
+        pw0[j] += pws[3 * i + j];
+      }
+    for (int j = 0; j < 3; j++) {
+      pc0[j] /= n;
+      pw0[j] /= n;
+    }
+    double abt[9];
+    for (int i = 0; i < 9; i++) abt[i] = 0;
+    for (int i = 0; i < n; i++) {
+      const double* pc = pcs + 3 * i;
+      const double* pw = pws + 3 * i;
+      for (int j = 0; j < 3; j++) {
+        abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+        abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+        abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+      }
+    }
+    epnp_Rt_from_abt(abt, pc0, pw0, Rv, tv);
+    PROF(7);
+    double sum2 = 0.0;
+    for (int i = 0; i < n; i++) sum2 += epnp_reproj_term(Rv, tv, pws + 3 * i, us[2 * i], us[2 * i + 1], cam);
+    err = sum2 / n;
+    PROF(8);
+  }
+  return err;
+}
+
+// ---- ordered sums over the correspondences, wave-cooperative ------------------------------------
+// out[k] = sum_i term(i)[k], accumulated in i order from 0.0 exactly like the reference's
+// sequential loops: the 64 lanes evaluate the terms of 64 consecutive i, park them in LDS, and
+// lane k (< K) adds them up in order.  `terms` holds 64 * (K | 1) doubles; all lanes must call.
+template <int K, typename F>
+__device__ __forceinline__ void ordered_sums(int n, ldsd* terms, ldsd* out, F&& term) {
+  constexpr int KP = K | 1;
+  const int lane = threadIdx.x & 63;
+  double acc = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    if (i < n) {
+      double tv[K];
+      term(i, tv);
+#pragma unroll
+      for (int k = 0; k < K; k++) terms[lane * KP + k] = tv[k];
+    }
+    __syncthreads();
+    const int cnt = min(64, n - base);
+    if (lane < K) {
+#pragma unroll 8
+      for (int j = 0; j < cnt; j++) acc += terms[j * KP + lane];
+    }
+    __syncthreads();
+  }
+  if (lane < K) out[lane] = acc;
+  __syncthreads();
+}
+
+// ---- EPnP refit over the best inlier set (n >= 4), one wave, all lanes call with identical args ----
+// Everything O(n) is spread over the lanes: per-correspondence work (alphas, pcs, reprojection
+// terms) is lane-parallel, every reduction is an ordered_sums (bit-identical to the sequential
+// loops of the reference).  M^T M: one lane per non-zero upper-triangle entry (62 of 78; the other
+// 16 pair an x- with a y-column of M and stay +0), inputs staged through LDS.  The 12 x 12 SVD
+// runs on lane 0, the three beta variants on lanes 0..2.  ut / L: lane 0's LDS views.
+// lds: terms[64 * 9], red[64], mtm[144].  Writes {R (row-major), t} to Rt_out[12] (LDS).
+template <typename Ptr>
+__device__ __noinline__ double epnp_refit_wave(int n, const double* pws, const double* us, double* alphas, double* pcs,
+                                               const EpnpCam cam, ldsd* Rt_out, Ptr ut, Ptr L, ldsd* terms, ldsd* red, ldsd* mtm) {
+  const int lane = threadIdx.x & 63;
+  double cws[4][3], ci[9];
+  PROF_DECL;
+  // choose_control_points
+  ordered_sums<3>(n, terms, red, [&](int i, double* tv) {
+    for (int k = 0; k < 3; k++) tv[k] = pws[3 * i + k];
+  });
+  for (int j = 0; j < 3; j++) cws[0][j] = red[j] / n;
+  ordered_sums<6>(n, terms, red, [&](int i, double* tv) {
+    const double d0 = pws[3 * i] - cws[0][0], d1 = pws[3 * i + 1] - cws[0][1], d2 = pws[3 * i + 2] - cws[0][2];
+    tv[0] = d0 * d0; tv[1] = d0 * d1; tv[2] = d0 * d2;
+    tv[3] = d1 * d1; tv[4] = d1 * d2; tv[5] = d2 * d2;
+  });
+  if (lane == 0) {
+    const double pw0tpw0[9] = {red[0], red[1], red[2], red[1], red[3], red[4], red[2], red[4], red[5]};
+    epnp_control_points(pw0tpw0, n, cws);
+    epnp_cc_inverse(cws, ci);
+    for (int i = 0; i < 9; i++) {
+      red[16 + i] = cws[1 + i / 3][i % 3];
+      red[32 + i] = ci[i];
+    }
+  }
+  __syncthreads();
+  for (int i = 0; i < 9; i++) {
+    cws[1 + i / 3][i % 3] = red[16 + i];
+    ci[i] = red[32 + i];
+  }
+  PROF(16);
+  // compute_barycentric_coordinates (lane-parallel; correspondence i always belongs to lane i % 64)
+  for (int i = lane; i < n; i += 64) epnp_alphas(pws + 3 * i, cws, ci, alphas + 4 * i);
+  for (int e = lane; e < 144; e += 64) mtm[e] = 0;
+  PROF(17);
+  // M^T M
+  {
+    int ea = 0, eb = 0, cnt = 0;
+    for (int a = 0; a < 12; a++)
+      for (int b = a; b < 12; b++) {
+        const int ca = a % 3, cb = b % 3;
+        if ((ca == 0 && cb == 1) || (ca == 1 && cb == 0)) continue;
+        if (cnt == lane) { ea = a; eb = b; }
+        cnt++;
+      }
+    const bool mine = lane < 62;
+    const int ka = ea / 3, ca = ea % 3, kb = eb / 3, cb = eb % 3;
+    const bool has1 = ca != 1 && cb != 1, has2 = ca != 0 && cb != 0;
+    double acc = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      __syncthreads();
+      if (i < n) {
+        ldsd* row = terms + lane * 7;
+        for (int k = 0; k < 4; k++) row[k] = alphas[4 * i + k];
+        row[4] = cam.uc - us[2 * i];
+        row[5] = cam.vc - us[2 * i + 1];
+      }
+      __syncthreads();
+      const int c = min(64, n - base);
+      if (mine) {
+#pragma unroll 4
+        for (int j = 0; j < c; j++) {
+          const ldsd* row = terms + j * 7;
+          const double aa = row[ka], ab = row[kb];
+          const double m1a = aa * (ca == 0 ? cam.fu : row[4]), m1b = ab * (cb == 0 ? cam.fu : row[4]);
+          const double m2a = aa * (ca == 1 ? cam.fv : row[5]), m2b = ab * (cb == 1 ? cam.fv : row[5]);
+          acc += has1 ? m1a * m1b : 0.0;
+          acc += has2 ? m2a * m2b : 0.0;
+        }
+      }
+    }
+    if (mine) {
+      mtm[ea * 12 + eb] = acc;
+      mtm[eb * 12 + ea] = acc;
+    }
+  }
+  __syncthreads();
+  PROF(18);
+  double rho[6];
+  if (lane == 0) {
+    for (int i = 0; i < 144; i++) ut[i] = mtm[i];
+    svd_sym12_inplace(ut);
+  }
+  PROF(19);
+  epnp_L_rho(ut, cws, L, rho, lane == 0);
+  __syncthreads();
+  PROF(20);
+  if (lane < 3) {
+    double betas[4];
+    epnp_betas(lane + 1, L, rho, betas);
+    for (int i = 0; i < 4; i++) red[4 * lane + i] = betas[i];
+  }
+  __syncthreads();
+  double betas3[3][4];
+  for (int i = 0; i < 12; i++) betas3[i / 4][i % 4] = red[i];
+  __syncthreads();
+  PROF(22);
+  double bestR[3][3], bestT[3], best_err = 0;
+  for (int variant = 1; variant <= 3; variant++) {
+    double ccs[4][3];
+    epnp_ccs(ut, betas3[variant - 1], ccs);
+    // compute_pcs + solve_for_sign (decided by correspondence 0, which lane 0 holds)
+    double pc_first = 0;
+    for (int i = lane; i < n; i += 64) {
       const double* a = alphas + 4 * i;
       double* pc = pcs + 3 * i;
       for (int j = 0; j < 3; j++) pc[j] = a[0] * ccs[0][j] + a[1] * ccs[1][j] + a[2] * ccs[2][j] + a[3] * ccs[3][j];
+      if (i == 0) pc_first = pc[2];
     }
-    if (pcs[2] < 0.0) {
-      for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 3; j++) ccs[i][j] = -ccs[i][j];
-      for (int i = 0; i < n; i++) {
+    const bool flip = __shfl(pc_first, 0) < 0.0;
+    if (flip)
+      for (int i = lane; i < n; i += 64) {
         pcs[3 * i] = -pcs[3 * i];
         pcs[3 * i + 1] = -pcs[3 * i + 1];
         pcs[3 * i + 2] = -pcs[3 * i + 2];
       }
-    }
-    double Rv[3][3], tv[3];
-    {
-      double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
-      for (int i = 0; i < n; i++)
-        for (int j = 0; j < 3; j++) {
-          pc0[j] += pcs[3 * i + j];
-          pw0[j] += pws[3 * i + j];
-        }
+    // estimate_R_and_t
+    double pc0[3], pw0[3], Rv[3][3], tv[3];
+    ordered_sums<6>(n, terms, red, [&](int i, double* t6) {
       for (int j = 0; j < 3; j++) {
-        pc0[j] /= n;
-        pw0[j] /= n;
+        t6[j] = pcs[3 * i + j];
+        t6[3 + j] = pws[3 * i + j];
       }
-      double abt[9], abt_d[3], u3[9], v3[9];
-      for (int i = 0; i < 9; i++) abt[i] = 0;
-      for (int i = 0; i < n; i++) {
-        const double* pc = pcs + 3 * i;
-        const double* pw = pws + 3 * i;
-        for (int j = 0; j < 3; j++) {
-          abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
-          abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
-          abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
-        }
-      }
-      svd_square(abt, 3, abt_d, u3, v3);
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) Rv[i][j] = u3[i] * v3[j] + u3[3 + i] * v3[3 + j] + u3[6 + i] * v3[6 + j];
-      const double det = Rv[0][0] * Rv[1][1] * Rv[2][2] + Rv[0][1] * Rv[1][2] * Rv[2][0] + Rv[0][2] * Rv[1][0] * Rv[2][1] -
-                         Rv[0][2] * Rv[1][1] * Rv[2][0] - Rv[0][1] * Rv[1][0] * Rv[2][2] - Rv[0][0] * Rv[1][2] * Rv[2][1];
-      if (det < 0) {
-        Rv[2][0] = -Rv[2][0];
-        Rv[2][1] = -Rv[2][1];
-        Rv[2][2] = -Rv[2][2];
-      }
-      tv[0] = pc0[0] - dot3(Rv[0], pw0);
-      tv[1] = pc0[1] - dot3(Rv[1], pw0);
-      tv[2] = pc0[2] - dot3(Rv[2], pw0);
+    });
+    for (int j = 0; j < 3; j++) {
+      pc0[j] = red[j] / n;
+      pw0[j] = red[3 + j] / n;
     }
-    double sum2 = 0.0;
-    for (int i = 0; i < n; i++) {
+    ordered_sums<9>(n, terms, red, [&](int i, double* t9) {
+      const double* pc = pcs + 3 * i;
       const double* pw = pws + 3 * i;
-      double Xc = dot3(Rv[0], pw) + tv[0];
-      double Yc = dot3(Rv[1], pw) + tv[1];
-      double inv_Zc = 1.0 / (dot3(Rv[2], pw) + tv[2]);
-      double ue = cam.uc + cam.fu * Xc * inv_Zc;
-      double ve = cam.vc + cam.fv * Yc * inv_Zc;
-      double u = us[2 * i], v = us[2 * i + 1];
-      sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+      for (int j = 0; j < 3; j++) {
+        t9[3 * j] = (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+        t9[3 * j + 1] = (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+        t9[3 * j + 2] = (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+      }
+    });
+    if (lane == 0) {
+      double abt[9];
+      for (int i = 0; i < 9; i++) abt[i] = red[i];
+      epnp_Rt_from_abt(abt, pc0, pw0, Rv, tv);
+      for (int i = 0; i < 9; i++) red[16 + i] = Rv[i / 3][i % 3];
+      for (int i = 0; i < 3; i++) red[25 + i] = tv[i];
     }
-    const double err = sum2 / n;
+    __syncthreads();
+    for (int i = 0; i < 9; i++) Rv[i / 3][i % 3] = red[16 + i];
+    for (int i = 0; i < 3; i++) tv[i] = red[25 + i];
+    PROF(23);
+    ordered_sums<1>(n, terms, red, [&](int i, double* t1) {
+      t1[0] = epnp_reproj_term(Rv, tv, pws + 3 * i, us[2 * i], us[2 * i + 1], cam);
+    });
+    const double err = red[0] / n;
+    __syncthreads();
+    PROF(24);
     // N = 1; if (e2 < e1) N = 2; if (e3 < e[N]) N = 3
     if (variant == 1 || err < best_err) {
       best_err = err;
@@ -720,11 +989,11 @@ __device__ __noinline__ double epnp_compute_pose(int n, const double* pws, const
       }
     }
   }
-  for (int i = 0; i < 3; i++) {
-    for (int j = 0; j < 3; j++) R[i][j] = bestR[i][j];
-    t[i] = bestT[i];
+  if (lane == 0) {
+    for (int i = 0; i < 9; i++) Rt_out[i] = bestR[i / 3][i % 3];
+    for (int i = 0; i < 3; i++) Rt_out[9 + i] = bestT[i];
   }
-  }  // lead
+  __syncthreads();
   return best_err;
 }
 
@@ -747,13 +1016,13 @@ __device__ __forceinline__ bool pnp_is_inlier(const double* Rt, const float* q /
 __global__ __launch_bounds__(64, 4) void k_pnp(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all,
                                             TrackBuffers tb, TrackCam tcam, const float* __restrict__ sigma2, PnpParams pp) {
   // gathered correspondences live in HBM (read-mostly, L2-resident): {u, v, X, Y, Z, maxErr} f32
-  __shared__ double s_work[PNP_CHUNK * (144 + 60)];   // per-lane EPnP matrices, lane-interleaved
+  __shared__ double s_work[PNP_CHUNK * (156 + 60)];   // per-hypothesis EPnP matrices, lane-interleaved
   __shared__ double s_Rt[PNP_CHUNK][12];
   __shared__ unsigned long long s_mask[PNP_CHUNK][PNP_WORDS];
   __shared__ unsigned long long s_best[PNP_WORDS], s_ref[PNP_WORDS];
   __shared__ int s_cnt[PNP_CHUNK];
   __shared__ double s_RtRef[12];
-  __shared__ double s_mtm[144];
+  __shared__ double s_mtm[144], s_terms[64 * 9], s_red[64];
   const int f = blockIdx.x, lane = threadIdx.x;
   const int cap = tb.kp_cap;
   const sd_keypoint* kps = kps_all + (size_t)f * cap;
@@ -767,9 +1036,11 @@ __global__ __launch_bounds__(64, 4) void k_pnp(const sd_keypoint* __restrict__ k
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   float* g_p = tb.pnp_pts + (size_t)f * cap * 6;
   uint16_t* g_idx = tb.pnp_kpidx + (size_t)f * cap;
-  const int wl = lane < PNP_CHUNK ? lane : 0;
-  const LArr w_ut{s_work + wl}, w_L{s_work + 144 * PNP_CHUNK + wl};
+  const int hyp = lane % PNP_CHUNK, variant = lane / PNP_CHUNK + 1;   // lanes >= 3 * PNP_CHUNK: no hypothesis
+  const LArr w_ut{LDS_PTR(s_work) + hyp}, w_L{LDS_PTR(s_work) + 156 * PNP_CHUNK + hyp};
+  const LArr r_ut{LDS_PTR(s_work)}, r_L{LDS_PTR(s_work) + 156 * PNP_CHUNK};             // the refit uses hypothesis 0's storage
 
+  PROF_DECL;
   for (int i = lane; i < cap; i += 64) inl_out[i] = 0;
   // ---- ctor gather, in keypoint order
   int N = 0;
@@ -794,6 +1065,7 @@ __global__ __launch_bounds__(64, 4) void k_pnp(const sd_keypoint* __restrict__ k
   }
   N = min(N, PNP_MAXN);
   __syncthreads();
+  PROF(10);
   // ---- SetRansacParameters
   float eps = pp.epsilon;
   int minInl = pp.min_inliers;
@@ -828,15 +1100,17 @@ __global__ __launch_bounds__(64, 4) void k_pnp(const sd_keypoint* __restrict__ k
   double* scratch = tb.pnp_scratch + (size_t)f * cap * 12;
 
   for (int c0 = 0; c0 < total; c0 += PNP_CHUNK) {
-    const int it = c0 + lane;
+    PROF(11);
+    const int it = c0 + hyp;
     const int nact = min(PNP_CHUNK, total - c0);
-    if (lane < nact) {
+    {
+      const bool active = lane < 3 * PNP_CHUNK && hyp < nact;
       // minimal set: 4 draws without replacement from mvAllIndices via swap-with-back removal
       int modp[4], modv[4], nmod = 0, size = N;
-      double pws[12], us[8], alphas[16], pcs[12];
-      for (int k = 0; k < pp.min_set && k < 4; k++) {
+      double pws[12], us[8];
+      for (int k = 0; k < 4; k++) {
         const int ridx = 4 * it + k;
-        const int r = ridx < pp.rand_per_frame ? rs[ridx] : 0;
+        const int r = (active && ridx < pp.rand_per_frame) ? rs[ridx] : 0;
         const int randi = (int)(((double)r / (2147483647.0 + 1.0)) * size + 0);
         int val = randi, backv = size - 1;
         for (int q = 0; q < nmod; q++) {
@@ -856,11 +1130,20 @@ __global__ __launch_bounds__(64, 4) void k_pnp(const sd_keypoint* __restrict__ k
         us[2 * k + 1] = q[1];
       }
       double R[3][3], t[3];
-      epnp_compute_pose<false>(4, pws, us, alphas, pcs, cam, R, t, w_ut, w_L);
-      for (int i = 0; i < 9; i++) s_Rt[lane][i] = R[i / 3][i % 3];
-      for (int i = 0; i < 3; i++) s_Rt[lane][9 + i] = t[i];
+      const double err = epnp_minimal(active, variant, pws, us, cam, R, t, w_ut, w_L);
+      // N = 1; if (e2 < e1) N = 2; if (e3 < e[N]) N = 3   (src/PnPsolver.cc:385-389)
+      const double e1 = __shfl(err, hyp), e2 = __shfl(err, hyp + PNP_CHUNK), e3 = __shfl(err, hyp + 2 * PNP_CHUNK);
+      int win = 1;
+      double be = e1;
+      if (e2 < be) { win = 2; be = e2; }
+      if (e3 < be) win = 3;
+      if (active && variant == win) {
+        for (int i = 0; i < 9; i++) s_Rt[hyp][i] = R[i / 3][i % 3];
+        for (int i = 0; i < 3; i++) s_Rt[hyp][9 + i] = t[i];
+      }
     }
     __syncthreads();
+    PROF(12);
     // inlier masks of the chunk's hypotheses
     for (int h = 0; h < nact; h++) {
       int cnt = 0;
@@ -875,6 +1158,7 @@ __global__ __launch_bounds__(64, 4) void k_pnp(const sd_keypoint* __restrict__ k
       if (lane == 0) s_cnt[h] = cnt;
     }
     __syncthreads();
+    PROF(13);
     // sequential accept / refine replay
     for (int h = 0; h < nact; h++) {
       const int cnt = s_cnt[h];
@@ -889,28 +1173,24 @@ __global__ __launch_bounds__(64, 4) void k_pnp(const sd_keypoint* __restrict__ k
         double* us = scratch + 3 * (size_t)cap;
         double* alphas = scratch + 5 * (size_t)cap;
         double* pcs = scratch + 9 * (size_t)cap;
-        if (lane == 0) {
-          int n = 0;
-          for (int i = 0; i < N; i++)
-            if ((s_best[i >> 6] >> (i & 63)) & 1ull) {
-              const float* q = g_p + (size_t)i * 6;
+        {
+          int n0 = 0;
+          for (int w = 0; w < nwords; w++) {
+            const unsigned long long bits = s_best[w];
+            if ((bits >> lane) & 1ull) {
+              const int n = n0 + __popcll(bits & lt);
+              const float* q = g_p + (size_t)(w * 64 + lane) * 6;
               pws[3 * n] = q[2];
               pws[3 * n + 1] = q[3];
               pws[3 * n + 2] = q[4];
               us[2 * n] = q[0];
               us[2 * n + 1] = q[1];
-              n++;
             }
-        }
-        __syncthreads();
-        {
-          double R[3][3], t[3];
-          epnp_compute_pose<true>(best, pws, us, alphas, pcs, cam, R, t, w_ut, w_L, s_mtm);   // best == popcount(s_best)
-          if (lane == 0) {
-            for (int i = 0; i < 9; i++) s_RtRef[i] = R[i / 3][i % 3];
-            for (int i = 0; i < 3; i++) s_RtRef[9 + i] = t[i];
+            n0 += __popcll(bits);
           }
         }
+        __syncthreads();
+        epnp_refit_wave(best, pws, us, alphas, pcs, cam, LDS_PTR(s_RtRef), r_ut, r_L, LDS_PTR(s_terms), LDS_PTR(s_red), LDS_PTR(s_mtm));   // best == popcount(s_best)
         __syncthreads();
         int rcnt = 0;
         for (int w = 0; w < nwords; w++) {
@@ -932,6 +1212,7 @@ __global__ __launch_bounds__(64, 4) void k_pnp(const sd_keypoint* __restrict__ k
       if (accepted) break;
     }
     __syncthreads();
+    PROF(14);
     if (accepted) break;
   }
   // ---- common tail (uniform control flow): write the returned pose and inlier flags
@@ -973,13 +1254,35 @@ __global__ __launch_bounds__(64, 4) void k_pnp(const sd_keypoint* __restrict__ k
 
 // diagnostics: EPnP alone on explicit correspondences (one lane)
 __global__ void k_epnp_debug(int n, const double* pws, const double* us, double* work, EpnpCam cam, double* out13) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double R[3][3], t[3];
-  double ut[144], L[60];
-  double e = epnp_compute_pose<false>(n, pws, us, work, work + 4 * (size_t)n, cam, R, t, (double*)ut, (double*)L);
-  for (int i = 0; i < 9; i++) out13[i] = R[i / 3][i % 3];
-  for (int i = 0; i < 3; i++) out13[9 + i] = t[i];
-  out13[12] = e;
+  __shared__ double s_work[PNP_CHUNK * (156 + 60)];
+  __shared__ double s_mtm[144], s_terms[64 * 9], s_red[64], s_Rt[12];
+  const int lane = threadIdx.x;
+  const LArr ut{LDS_PTR(s_work)}, L{LDS_PTR(s_work) + 156 * PNP_CHUNK};
+  double e;
+  if (n == 4) {   // the RANSAC minimal-set solver: lanes 0, PNP_CHUNK, 2 * PNP_CHUNK run the three variants
+    double R[3][3], t[3], p[12], u[8];
+    for (int i = 0; i < 12; i++) p[i] = pws[i];
+    for (int i = 0; i < 8; i++) u[i] = us[i];
+    const int hyp = lane % PNP_CHUNK, variant = lane / PNP_CHUNK + 1;
+    const bool active = hyp == 0 && variant <= 3;
+    const double err = epnp_minimal(active, variant, p, u, cam, R, t, ut, L);
+    const double e1 = __shfl(err, 0), e2 = __shfl(err, PNP_CHUNK), e3 = __shfl(err, 2 * PNP_CHUNK);
+    int win = 1;
+    e = e1;
+    if (e2 < e) { win = 2; e = e2; }
+    if (e3 < e) { win = 3; e = e3; }
+    if (active && variant == win) {
+      for (int i = 0; i < 9; i++) s_Rt[i] = R[i / 3][i % 3];
+      for (int i = 0; i < 3; i++) s_Rt[9 + i] = t[i];
+    }
+    __syncthreads();
+  } else {
+    e = epnp_refit_wave(n, pws, us, work, work + 4 * (size_t)n, cam, LDS_PTR(s_Rt), ut, L, LDS_PTR(s_terms), LDS_PTR(s_red), LDS_PTR(s_mtm));
+  }
+  if (lane == 0) {
+    for (int i = 0; i < 12; i++) out13[i] = s_Rt[i];
+    out13[12] = e;
+  }
 }
 
 int run_epnp_debug(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy, double* R9, double* t3,
@@ -1000,6 +1303,21 @@ int run_epnp_debug(int n, const double* Xw, const double* uv, double fx, double 
   if (err) *err = out[12];
   (void)hipFree(d_p); (void)hipFree(d_u); (void)hipFree(d_w); (void)hipFree(d_o);
   return SD_OK;
+}
+
+int read_pnp_prof(unsigned long long* out32, int reset) {
+#ifdef SD_PNP_PROF
+  SD_HIP_CHECK(hipDeviceSynchronize());
+  SD_HIP_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_pnp_prof), 32 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[32] = {};
+    SD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_pnp_prof), z, sizeof(z)));
+  }
+  return SD_OK;
+#else
+  set_error("library built without -DSD_PNP_PROF");
+  return SD_ERR_INVALID_ARG;
+#endif
 }
 
 int launch_pnp(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sigma2, const PnpParams& pp,
