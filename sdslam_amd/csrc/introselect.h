@@ -142,4 +142,17 @@ SD_HD void nth_element(uint32_t* a, int n, int nth) {
   insertion_sort(a, first, last);
 }
 
+// ---- bulk (data-parallel) formulation of the unguarded Hoare partition ---------------------------
+// The sequential partition loop
+//     while (true) { while (gt(a[lo], p)) ++lo;  --hi;  while (gt(p, a[hi])) --hi;
+//                    if (!(lo < hi)) return lo;  swap(a[lo], a[hi]);  ++lo; }
+// only ever swaps the k-th "left stop" L_k (k-th position from the left, in the ORIGINAL array, whose
+// element is not gt the pivot) with the k-th "right stop" R_k (k-th position from the right whose
+// element the pivot is not gt), for k = 0 .. K-1 where K is the first k with !(L_k < R_k): both scans
+// run over elements no swap has touched yet.  The returned cut is L_K if it lies below R_{K-1}, else
+// R_{K-1} (which by then holds a left-stop value); L_0 when K == 0.  So a wavefront can compute both
+// stop sets with ballots, pair them by rank and apply all swaps at once (introselect_wave.h).
+// tests/native/introselect_check.cc states this formulation on a snapshot of the array and checks it
+// against std::nth_element.
+
 }  // namespace sdsel

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "introselect.h"
+#include "introselect_wave.h"
 #include "orb_plan.h"
 #include "sd_common.h"
 #include "sd_sincosf.h"
@@ -466,32 +467,51 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_select_level: one workgroup per (level, frame).
-//   1. quota redistribution loop            src/ORBextractor.cc:541-575 (serial, lane 0)
-//   2. per-cell retainBest + resize         :586-588   (one lane per cell, introselect replay)
-//   3. concatenation in cell raster order   :591-597
-//   4. level-wide retainBest + resize       :601-604   (lane 0)
-// Candidate lists are staged in LDS when the level fits, else processed in place in HBM.
+// k_select_level: one workgroup (4 waves) per (level, frame).
+//   1. quota redistribution loop            src/ORBextractor.cc:541-575 (serial, thread 0)
+//   2. per-cell retainBest + resize         :586-588   one WAVE per cell: the cell's candidates are
+//      staged into the wave's LDS buffer, trimmed with the wave-parallel introselect replay
+//      (introselect_wave.h) and the survivors written straight to their slot of the level list
+//      (:591-597; the kept counts, hence the offsets, are known after step 1)
+//   3. level-wide retainBest + resize       :601-604   wave 0, same replay, list in LDS
+// Cells with more candidates than the wave buffer, or levels whose list exceeds the LDS list, fall
+// back to the serial replay in HBM (never seen on VGA frames; kept for correctness).
 // ------------------------------------------------------------------------------------------
-// LDS budget ~28 KB per workgroup (5 per CU); denser levels fall back to in-place HBM lists
-#define SEL_WORK_CAP 4096
-#define SEL_LIST_CAP 1536
-#define SEL_MAX_CELLS 512
+#ifdef SD_PNP_PROF   // stage timers (tools/prof_select.py): cycles of thread 0, [level][slot], summed over frames
+__device__ unsigned long long g_sel_prof[64];
+#define SPROF_DECL long long _pt = clock64()
+#define SPROF(i)                                                                                        \
+  do {                                                                                                  \
+    long long _n = clock64();                                                                           \
+    if (threadIdx.x == 0) atomicAdd(&g_sel_prof[blockIdx.x * 8 + (i)], (unsigned long long)(_n - _pt)); \
+    _pt = _n;                                                                                           \
+  } while (0)
+#else
+#define SPROF_DECL
+#define SPROF(i)
+#endif
 
-__global__ __launch_bounds__(256) void k_select_level(const OrbPlan* __restrict__ P,
-                                                      const CellGeom* __restrict__ cells,
-                                                      uint32_t* __restrict__ cand,
-                                                      const int32_t* __restrict__ cell_count,
-                                                      uint32_t* __restrict__ lvl_scratch,
-                                                      uint32_t* __restrict__ sel,
-                                                      int32_t* __restrict__ sel_count) {
-  __shared__ uint32_t s_work[SEL_WORK_CAP];
+#define SEL_WAVES 4
+#define SEL_CELL_CAP 1024   // candidates of one cell staged per wave (LDS)
+#define SEL_LIST_CAP 1536   // level list (LDS)
+#define SEL_MAX_CELLS 512
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+__global__ __launch_bounds__(64 * SEL_WAVES) void k_select_level(const OrbPlan* __restrict__ P,
+                                                                const CellGeom* __restrict__ cells,
+                                                                uint32_t* __restrict__ cand,
+                                                                const int32_t* __restrict__ cell_count,
+                                                                uint32_t* __restrict__ lvl_scratch,
+                                                                uint32_t* __restrict__ sel,
+                                                                int32_t* __restrict__ sel_count) {
+  __shared__ uint32_t s_buf[SEL_WAVES][SEL_CELL_CAP];
   __shared__ uint32_t s_list[SEL_LIST_CAP];
+  __shared__ uint16_t s_tmp[SEL_WAVES][2 * WAVE_SEL_CAP];   // stop tables of the wave-parallel partition
   __shared__ int s_total[SEL_MAX_CELLS];
   __shared__ int s_retain[SEL_MAX_CELLS];
-  __shared__ int s_off[SEL_MAX_CELLS + 1];   // work offsets, then kept offsets
-  __shared__ int s_flag;
-  const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+  __shared__ int s_off[SEL_MAX_CELLS + 1];   // bNoMore flags during the quota loop, then kept offsets
+  __shared__ int s_M;
+  const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const LevelGeom L = P->lv[level];
   int32_t* out_n = sel_count + (size_t)frame * P->nlevels + level;
   if (L.ncells <= 0 || L.quota <= 0) {
@@ -503,15 +523,20 @@ __global__ __launch_bounds__(256) void k_select_level(const OrbPlan* __restrict_
   const int32_t* cc = cell_count + (size_t)frame * P->ncells + L.cell0;
   uint32_t* gcand = cand + (size_t)frame * P->cand_per_frame;
 
-  for (int c = tid; c < nC; c += 256) s_total[c] = cc[c];
+  SPROF_DECL;
+  for (int c = tid; c < nC; c += 64 * SEL_WAVES) {
+    s_total[c] = cc[c];
+    s_off[c] = cg[c].evaluated;
+  }
   __syncthreads();
+  SPROF(0);
   if (tid == 0) {
     // quota loop (serial by definition)
     const int nfc = L.nfeaturesCell;
     int nNoMore = 0, nToDistribute = 0;
     for (int c = 0; c < nC; c++) {
       int nKeys = s_total[c];
-      if (!cg[c].evaluated) {          // reference `continue`s: nToRetain=0, bNoMore=false
+      if (!s_off[c]) {                 // cell not evaluated: the reference `continue`s (nToRetain=0, bNoMore=false)
         s_retain[c] = 0;
         s_off[c] = 0;                  // bNoMore flag lives in s_off during the loop
         continue;
@@ -543,65 +568,71 @@ __global__ __launch_bounds__(256) void k_select_level(const OrbPlan* __restrict_
         }
       }
     }
-    // work offsets + kept counts
-    int wo = 0, kept = 0;
-    for (int c = 0; c < nC; c++) {
-      s_off[c] = wo;
-      wo += s_total[c];
-      kept += min(s_total[c], s_retain[c]);
-    }
-    s_off[nC] = wo;
-    s_flag = (wo <= SEL_WORK_CAP ? 1 : 0) | (kept <= SEL_LIST_CAP ? 2 : 0);
-  }
-  __syncthreads();
-  const bool work_lds = s_flag & 1, list_lds = s_flag & 2;
-  // stage candidates into LDS (cell lists become contiguous)
-  if (work_lds) {
-    for (int c = 0; c < nC; c++) {
-      const uint32_t* src = gcand + cg[c].cand_off;
-      const int n = s_total[c], o = s_off[c];
-      for (int i = tid; i < n; i += 256) s_work[o + i] = src[i];
-    }
-  }
-  __syncthreads();
-  // per-cell retainBest (one lane per cell)
-  for (int c = tid; c < nC; c += 256) {
-    int n = s_total[c], keep = s_retain[c];
-    if (n > keep && keep > 0) {
-      uint32_t* a = work_lds ? (s_work + s_off[c]) : (gcand + cg[c].cand_off);
-      sdsel::nth_element(a, n, keep);
-    }
-  }
-  __syncthreads();
-  // kept offsets (serial prefix, tiny) -- reuse s_retain as kept count
-  if (tid == 0) {
+    // kept counts and their offsets in the level list
     int o = 0;
     for (int c = 0; c < nC; c++) {
-      int k = min(s_total[c], s_retain[c]);
-      s_retain[c] = k;
-      s_total[c] = o;   // kept offset
-      o += k;
+      s_off[c] = o;
+      o += min(s_total[c], s_retain[c]);
     }
-    s_flag = o;          // M
+    s_off[nC] = o;
+    s_M = o;
   }
   __syncthreads();
-  const int M = s_flag;
-  uint32_t* list = list_lds ? s_list : (lvl_scratch + (size_t)frame * P->cand_per_frame + L.cand_off);
-  for (int c = 0; c < nC; c++) {
-    const uint32_t* a = work_lds ? (s_work + s_off[c]) : (gcand + cg[c].cand_off);
-    const int k = s_retain[c], o = s_total[c];
-    for (int i = tid; i < k; i += 256) list[o + i] = a[i];
+  SPROF(1);
+  const int M = s_M;
+  const bool list_lds = M <= SEL_LIST_CAP;
+  uint32_t* glist = lvl_scratch + (size_t)frame * P->cand_per_frame + L.cand_off;
+  // ---- per-cell retainBest, one wave per cell
+  {
+    lds_u32* buf = (lds_u32*)s_buf[wave];
+    for (int c = wave; c < nC; c += SEL_WAVES) {
+      const int n = s_total[c], keep = min(n, s_retain[c]), o = s_off[c];
+      if (keep <= 0) continue;
+      uint32_t* src = gcand + cg[c].cand_off;
+      if (n <= SEL_CELL_CAP) {
+        for (int i = lane; i < n; i += 64) buf[i] = src[i];
+        sdsel::wave_fence();
+        if (n > keep) sdsel::wave_nth_element(buf, n, keep, (sdsel::lds_u16*)s_tmp[wave]);
+        if (list_lds) {
+          for (int i = lane; i < keep; i += 64) s_list[o + i] = buf[i];
+        } else {
+          for (int i = lane; i < keep; i += 64) glist[o + i] = buf[i];
+        }
+        sdsel::wave_fence();   // buf is reused by this wave's next cell
+      } else {
+        if (lane == 0) {
+          if (n > keep) sdsel::nth_element(src, n, keep);
+          for (int i = 0; i < keep; i++) {
+            if (list_lds) s_list[o + i] = src[i];
+            else glist[o + i] = src[i];
+          }
+        }
+      }
+    }
   }
   __syncthreads();
+  SPROF(3);
+  // ---- level-wide retainBest
   int Mout = M;
   if (M > L.quota) {
-    if (tid == 0) sdsel::nth_element(list, M, L.quota);
+    if (list_lds) {
+      if (wave == 0) sdsel::wave_nth_element((lds_u32*)s_list, M, L.quota, (sdsel::lds_u16*)s_tmp[0]);
+    } else if (tid == 0) {
+      __threadfence_block();
+      sdsel::nth_element(glist, M, L.quota);
+    }
     Mout = L.quota;
   }
   __syncthreads();
+  SPROF(5);
   uint32_t* dst = sel + (size_t)frame * P->nsel + L.sel_off;
-  for (int i = tid; i < Mout; i += 256) dst[i] = list[i];
+  if (list_lds) {
+    for (int i = tid; i < Mout; i += 64 * SEL_WAVES) dst[i] = s_list[i];
+  } else {
+    for (int i = tid; i < Mout; i += 64 * SEL_WAVES) dst[i] = glist[i];
+  }
   if (tid == 0) *out_n = Mout;
+  SPROF(6);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -922,7 +953,7 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
                        h->d_pyr, h->d_cand, h->d_cell_count);
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[2], s));
-  hipLaunchKernelGGL(k_select_level, dim3(P.nlevels, n), dim3(256), 0, s, h->d_plan, h->d_cells, h->d_cand,
+  hipLaunchKernelGGL(k_select_level, dim3(P.nlevels, n), dim3(64 * SEL_WAVES), 0, s, h->d_plan, h->d_cells, h->d_cand,
                      h->d_cell_count, h->d_scratch, h->d_sel, h->d_sel_count);
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[7], s));
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_blur_done, 0));
@@ -943,6 +974,23 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   h->last_frames = n;
   return SD_OK;
 }
+
+namespace sd {
+int read_sel_prof(unsigned long long* out64, int reset) {
+#ifdef SD_PNP_PROF
+  SD_HIP_CHECK(hipDeviceSynchronize());
+  SD_HIP_CHECK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_sel_prof), 64 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[64] = {};
+    SD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sel_prof), z, sizeof(z)));
+  }
+  return SD_OK;
+#else
+  set_error("library built without -DSD_PNP_PROF");
+  return SD_ERR_INVALID_ARG;
+#endif
+}
+}  // namespace sd
 
 extern "C" {
 

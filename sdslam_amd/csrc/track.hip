@@ -361,6 +361,11 @@ int sd_debug_pnp_prof(unsigned long long* out32, int reset) {
   return read_pnp_prof(out32, reset);
 }
 
+int sd_debug_sel_prof(unsigned long long* out64, int reset) {
+  SD_REQUIRE(out64, SD_ERR_INVALID_ARG, "null output");
+  return read_sel_prof(out64, reset);
+}
+
 int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy, double* R9, double* t3,
                   double* reproj_err) {
   SD_REQUIRE(n >= 4 && Xw && uv && R9 && t3, SD_ERR_INVALID_ARG, "bad arguments");

@@ -1013,7 +1013,7 @@ __device__ __forceinline__ bool pnp_is_inlier(const double* Rt, const float* q /
   return error2 < maxErr;
 }
 
-__global__ __launch_bounds__(64, 4) void k_pnp(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all,
+__global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all,
                                             TrackBuffers tb, TrackCam tcam, const float* __restrict__ sigma2, PnpParams pp) {
   // gathered correspondences live in HBM (read-mostly, L2-resident): {u, v, X, Y, Z, maxErr} f32
   __shared__ double s_work[PNP_CHUNK * (156 + 60)];   // per-hypothesis EPnP matrices, lane-interleaved

@@ -63,3 +63,69 @@ extern "C" long introselect_heap_cases(int seed, int tries, long* heap_calls_out
   *heap_calls_out = g_heap_calls;
   return bad;
 }
+
+// ---- the bulk (ballot-style) partition formulation of introselect.h / introselect_wave.h ----------
+// Stops are taken from a SNAPSHOT of the range, paired by rank, all swaps applied at once.
+static int partition_snapshot(uint32_t* a, int lo0, int hi0, uint32_t pivot) {
+  std::vector<int> Ls, Rs;
+  for (int i = lo0; i < hi0; i++)
+    if (!sdsel::gt(a[i], pivot)) Ls.push_back(i);
+  for (int j = hi0 - 1; j >= lo0; j--)
+    if (!sdsel::gt(pivot, a[j])) Rs.push_back(j);
+  size_t K = 0;
+  while (K < Ls.size() && K < Rs.size() && Ls[K] < Rs[K]) K++;
+  for (size_t k = 0; k < K; k++) std::swap(a[Ls[k]], a[Rs[k]]);
+  const int BIG = 0x7fffffff;
+  const int LK = K < Ls.size() ? Ls[K] : BIG, Rprev = K > 0 ? Rs[K - 1] : BIG;
+  return LK < Rprev ? LK : Rprev;
+}
+
+static void nth_element_snapshot(uint32_t* a, int n, int nth) {
+  using namespace sdsel;
+  if (n <= 0 || nth >= n) return;
+  int first = 0, last = n;
+  int depth = 2 * (31 - __builtin_clz((unsigned)n));
+  while (last - first > 3) {
+    if (depth == 0) {
+      heap_select(a + first, nth + 1 - first, last - first);
+      swp(a, first, nth);
+      return;
+    }
+    --depth;
+    int mid = first + (last - first) / 2;
+    {
+      const int r = first, ia = first + 1, ib = mid, ic = last - 1;
+      if (gt(a[ia], a[ib])) {
+        if (gt(a[ib], a[ic])) swp(a, r, ib);
+        else if (gt(a[ia], a[ic])) swp(a, r, ic);
+        else swp(a, r, ia);
+      } else if (gt(a[ia], a[ic])) swp(a, r, ia);
+      else if (gt(a[ib], a[ic])) swp(a, r, ic);
+      else swp(a, r, ib);
+    }
+    const int cut = partition_snapshot(a, first + 1, last, a[first]);
+    if (cut <= nth) first = cut;
+    else last = cut;
+  }
+  insertion_sort(a, first, last);
+}
+
+extern "C" long introselect_snapshot_selftest(int seed, int ncases, int maxn, int resp_span) {
+  std::mt19937 rng(seed);
+  long bad = 0;
+  for (int c = 0; c < ncases; c++) {
+    int n = 1 + rng() % maxn;
+    std::vector<uint32_t> keys(n);
+    int span = 1 + rng() % resp_span;
+    for (int i = 0; i < n; i++) keys[i] = ((20u + rng() % span) << 24) | ((uint32_t)(i / 64) << 12) | (uint32_t)(i % 64);
+    int mode = rng() % 4;
+    if (mode == 1) std::sort(keys.begin(), keys.end());
+    if (mode == 2) std::sort(keys.begin(), keys.end(), std::greater<uint32_t>());
+    int nth = rng() % n;
+    std::vector<uint32_t> a = keys, b = keys;
+    sdsel::nth_element(a.data(), n, nth);
+    nth_element_snapshot(b.data(), n, nth);
+    if (a != b) bad++;
+  }
+  return bad;
+}

@@ -119,6 +119,10 @@ def test_introselect_replays_libstdcxx_nth_element():
     assert L.introselect_selftest(2, 60000, 40, 6) == 0
     heap_calls = C.c_long()
     assert L.introselect_heap_cases(3, 60000, C.byref(heap_calls)) == 0
+    # the data-parallel (snapshot / ballot) formulation the wave kernels use gives the same permutation
+    L.introselect_snapshot_selftest.restype = C.c_long
+    assert L.introselect_snapshot_selftest(5, 4000, 3000, 40) == 0
+    assert L.introselect_snapshot_selftest(6, 60000, 70, 6) == 0
     assert heap_calls.value > 100      # the depth-limit / heap_select fallback really was exercised
 
 

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Stage cycle counters of k_select_level on the bench frames (library built with
+SD_EXTRA_FLAGS=-DSD_PNP_PROF).  Cycles of thread 0 per (level, stage), averaged per frame."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+import sdslam_amd  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+scenes = bench.make_cases(8, 1000)
+frames = np.stack([scenes[i % 8]["cur"] for i in range(B)])
+cur = sdslam_amd.ORBextractor(*bench.CFG, bench.W, bench.H, B)
+L = sdslam_amd.capi.lib()
+out = (C.c_ulonglong * 64)()
+cur.extract_batch(frames)
+assert L.sd_debug_sel_prof(out, 1) == 0, "library built without -DSD_PNP_PROF"
+reps = 3
+for _ in range(reps):
+    cur.extract_batch(frames)
+assert L.sd_debug_sel_prof(out, 1) == 0
+v = (np.array(list(out), np.float64) / (B * reps)).reshape(8, 8)
+names = ["load counts", "quota loop", "-", "per-cell retainBest", "-", "level retainBest", "write"]
+print("level " + " ".join(f"{n:>20s}" for n in names) + "        total")
+for l in range(8):
+    print(f"{l:5d} " + " ".join(f"{v[l, i]:20.0f}" for i in range(7)) + f" {v[l, :7].sum():12.0f}")
+print("sum   " + " ".join(f"{v[:, i].sum():20.0f}" for i in range(7)) + f" {v[:, :7].sum():12.0f}")
