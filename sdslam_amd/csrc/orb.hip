@@ -312,6 +312,20 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t* __restrict__ c, 
   return max(a, -b) - 1;
 }
 
+#ifdef SD_PNP_PROF   // stage timers of k_fast_cells (tools/prof_select.py --fast): cycles of thread 0 per phase
+__device__ unsigned long long g_fast_prof[8];
+#define FPROF_DECL long long _pt = clock64()
+#define FPROF(i)                                                                             \
+  do {                                                                                       \
+    long long _n = clock64();                                                                \
+    if (threadIdx.x == 0) atomicAdd(&g_fast_prof[i], (unsigned long long)(_n - _pt));        \
+    _pt = _n;                                                                                \
+  } while (0)
+#else
+#define FPROF_DECL
+#define FPROF(i)
+#endif
+
 // Structure of one strip (a cell is one strip unless it is too large for LDS):
 //   A. every wave owns a contiguous band of rows; per 64-px row segment a 4-read compass test
 //      (a 9-arc always contains two ADJACENT compass points of the same polarity) rejects most
@@ -352,6 +366,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
   const unsigned magic = 0xFFFFFFFFu / (unsigned)zw + 1u;   // q / zw == umulhi(q, magic) for q < 2^16, zw < 2^12
   const unsigned long long lt = lanemask_lt();
   int total = 0;
+  FPROF_DECL;
 
   for (int r0 = 0; r0 < zh; r0 += S) {
     const int r1 = min(r0 + S, zh);
@@ -361,13 +376,26 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
     // ---- stage pixels (aligned words) and clear the score map
     {
       const uint8_t* g = img + (size_t)(C.zy0 + sr0 - 3 + SD_EDGE) * L.pstride + xa;
-      for (int row = wave; row < npr; row += 4)
-        for (int wc = lane; wc < TPW; wc += 64)
-          ((uint32_t*)tile)[__mul24(row, TPW) + wc] = *(const uint32_t*)(g + (size_t)__mul24(row, L.pstride) + wc * 4);
+      // loads are issued 8 rows at a time before the first LDS store: one global round trip per batch
+      for (int wc = lane; wc < TPW; wc += 64)
+        for (int row0 = wave; row0 < npr; row0 += 32) {
+          uint32_t v[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const int row = row0 + 4 * j;
+            v[j] = row < npr ? *(const uint32_t*)(g + (size_t)__mul24(row, L.pstride) + wc * 4) : 0u;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const int row = row0 + 4 * j;
+            if (row < npr) ((uint32_t*)tile)[__mul24(row, TPW) + wc] = v[j];
+          }
+        }
       const int nsc = ((nsr + 2) * SP) >> 2;
       for (int i = tid; i < nsc; i += 256) ((uint32_t*)sc)[i] = 0;
     }
     __syncthreads();
+    FPROF(0);
     // ---- A: compass quick test, ordered queue per wave
     const int rpw = (nsr + 3) >> 2;
     const int y_lo = min(wave * rpw, nsr), y_hi = min(y_lo + rpw, nsr);
@@ -379,18 +407,19 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
         bool pass = false;
         if (x < zw) {
           const uint8_t* c = rowc + x;
-          const int v = c[0];
-          const int d0 = v - c[3 * TP], d4 = v - c[3], d8 = v - c[-3 * TP], d12 = v - c[-3];
-          const unsigned dk = (unsigned)(d0 > th) | ((unsigned)(d4 > th) << 1) | ((unsigned)(d8 > th) << 2) | ((unsigned)(d12 > th) << 3);
-          const unsigned br = (unsigned)(d0 < -th) | ((unsigned)(d4 < -th) << 1) | ((unsigned)(d8 < -th) << 2) | ((unsigned)(d12 < -th) << 3);
-          const unsigned dr = ((dk << 1) | (dk >> 3)) & 15u, brr = ((br << 1) | (br >> 3)) & 15u;
-          pass = ((dk & dr) | (br & brr)) != 0;
+          const int v = c[0], lo = v - th, hi = v + th;
+          const int p0 = c[3 * TP], p4 = c[3], p8 = c[-3 * TP], p12 = c[-3];
+          // comparisons stay lane masks (v_cmp -> SGPR pair) and are combined on the scalar unit
+          const bool k0 = p0 < lo, k4 = p4 < lo, k8 = p8 < lo, k12 = p12 < lo;
+          const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
+          pass = ((k0 | k8) & (k4 | k12)) | ((b0 | b8) & (b4 | b12));
         }
         const unsigned long long m = __ballot(pass);
         if (pass) queue[qn + __popcll(m & lt)] = (uint16_t)(__mul24(y, zw) + x);
         qn += __popcll(m);
       }
     }
+    FPROF(1);
     // ---- B1: full 9-contiguous test on the queued pixels; corners re-compacted in place
     int cn = 0;
     for (int e0 = 0; e0 < qn; e0 += 64) {
@@ -407,6 +436,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
       cn += __popcll(m);
     }
     qn = cn;
+    FPROF(2);
     // ---- B2: scores of the corners (dense)
     for (int e0 = 0; e0 < qn; e0 += 64) {
       const int e = e0 + lane;
@@ -417,7 +447,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
         if (s > 0) sc[__mul24(y + 1, SP) + x + 1] = (uint8_t)s;
       }
     }
+    FPROF(3);
     __syncthreads();
+    FPROF(4);
     // ---- C: NMS + ordered emission
     {
       unsigned long long bits = 0;
@@ -461,7 +493,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
       }
       total += strip_total;
     }
+    FPROF(5);
     __syncthreads();
+    FPROF(6);
   }
   if (tid == 0) cell_count[(size_t)frame * P->ncells + blockIdx.x] = min(total, (int)C.cap);
 }
@@ -976,13 +1010,17 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
 }
 
 namespace sd {
-int read_sel_prof(unsigned long long* out64, int reset) {
+int read_sel_prof(unsigned long long* out64, int reset) {   // [0..55] select [level][slot<7], [56..63] FAST phases
 #ifdef SD_PNP_PROF
   SD_HIP_CHECK(hipDeviceSynchronize());
   SD_HIP_CHECK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_sel_prof), 64 * sizeof(unsigned long long)));
+  unsigned long long f[8];
+  SD_HIP_CHECK(hipMemcpyFromSymbol(f, HIP_SYMBOL(g_fast_prof), sizeof(f)));
+  for (int l = 0; l < 8; l++) out64[l * 8 + 7] = f[l];   // slot 7 of every level row carries FAST phase l
   if (reset) {
     unsigned long long z[64] = {};
     SD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sel_prof), z, sizeof(z)));
+    SD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fast_prof), z, 8 * sizeof(unsigned long long)));
   }
   return SD_OK;
 #else

@@ -29,3 +29,8 @@ print("level " + " ".join(f"{n:>20s}" for n in names) + "        total")
 for l in range(8):
     print(f"{l:5d} " + " ".join(f"{v[l, i]:20.0f}" for i in range(7)) + f" {v[l, :7].sum():12.0f}")
 print("sum   " + " ".join(f"{v[:, i].sum():20.0f}" for i in range(7)) + f" {v[:, :7].sum():12.0f}")
+fn = ["stage+clear", "A compass", "B1 ring test", "B2 scores", "(barrier)", "C nms+emit", "(barrier)"]
+print("k_fast_cells, cycles of thread 0 per frame (sum over the 148 cells):")
+for i, n in enumerate(fn):
+    print(f"  {n:16s} {v[i, 7]:12.0f}")
+print(f"  {'total':16s} {v[:7, 7].sum():12.0f}")
