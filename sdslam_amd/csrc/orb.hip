@@ -234,6 +234,118 @@ __global__ __launch_bounds__(256) void k_pyr_level(const LevelGeom L, const Leve
 }
 
 // ------------------------------------------------------------------------------------------
+// Split pyramid construction (the default path).  k_pyr_level above evaluates every padded pixel
+// through one code path, so the waves at both ends of a row run the slow reflected-border branch
+// as well as the interior one.  Here:
+//   k_pyr_resize  interior pixels only (padded columns 20 + 4g, interior rows), no reflection, no
+//                 divergence: coefficient tables (the host's cv::resize tables), one aligned
+//                 12-byte window per source row, v_perm_b32 gathers the 2 x 4 source bytes;
+//   k_pyr_edges   the few interior pixels left of / right of the aligned groups and the left /
+//                 right REFLECT_101 borders of the interior rows, via pyr_px4 (generic path);
+//   k_pyr_rows    top / bottom border rows: copies of (complete) interior rows.
+// Level 0 is the frame copied into the padded layout by the same three kernels.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const LevelGeom S, size_t pyr_frame_bytes, int level,
+                                                    const int32_t* __restrict__ coef, const uint8_t* __restrict__ src0,
+                                                    int src_stride, size_t src_frame_stride, uint8_t* __restrict__ pyr,
+                                                    int G, unsigned magicG) {
+  const int frame = blockIdx.y;
+  const unsigned e = blockIdx.x * 256 + threadIdx.x;
+  const unsigned Y = __umulhi(e, magicG);        // e / G
+  if (Y >= (unsigned)L.h) return;
+  const int g = (int)(e - Y * (unsigned)G);
+  const int X0 = 1 + 4 * g;
+  uint8_t* dst = pyr + (size_t)frame * pyr_frame_bytes + L.off + (size_t)(Y + SD_EDGE) * L.pstride + (X0 + SD_EDGE);
+  uint32_t packed;
+  if (level == 0) {
+    const uint8_t* s = src0 + (size_t)frame * src_frame_stride + (size_t)Y * src_stride + X0;
+    const uintptr_t a = (uintptr_t)s;
+    const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+    packed = __builtin_amdgcn_alignbyte(q[1], q[0], (unsigned)(a & 3));
+  } else {
+    const int32_t* xo = coef + L.cx;
+    const int32_t* xa = xo + L.w;
+    const int32_t* yo = coef + L.cy;
+    const int32_t* yb = yo + L.h;
+    int sx[4];
+    uint32_t ab[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      sx[k] = xo[X0 + k];
+      ab[k] = (uint32_t)xa[X0 + k];
+    }
+    int sy0 = yo[Y];
+    const uint32_t bb = (uint32_t)yb[Y];
+    const int b0 = (int)(bb & 0xffff), b1 = (int)(bb >> 16);
+    int sy1 = sy0 + 1;
+    sy0 = sy0 < S.h ? sy0 : S.h - 1;
+    sy1 = sy1 < S.h ? sy1 : S.h - 1;
+    const uint8_t* sb = pyr + (size_t)frame * pyr_frame_bytes + S.off + (size_t)SD_EDGE * S.pstride + SD_EDGE;
+    const int base = sx[0];
+    const uintptr_t a0 = (uintptr_t)(sb + (size_t)__mul24(sy0, S.pstride) + base);
+    const uintptr_t a1 = (uintptr_t)(sb + (size_t)__mul24(sy1, S.pstride) + base);
+    const unsigned sh = (unsigned)(a0 & 3);   // same for both rows: the row pitch is a multiple of 64
+    const uint32_t* q0 = (const uint32_t*)(a0 & ~(uintptr_t)3);
+    const uint32_t* q1 = (const uint32_t*)(a1 & ~(uintptr_t)3);
+    const uint32_t u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
+    // 8 source bytes starting at sx[0], per row
+    const uint32_t r0lo = __builtin_amdgcn_alignbyte(u1, u0, sh), r0hi = __builtin_amdgcn_alignbyte(u2, u1, sh);
+    const uint32_t r1lo = __builtin_amdgcn_alignbyte(v1, v0, sh), r1hi = __builtin_amdgcn_alignbyte(v2, v1, sh);
+    uint32_t selA = 0, selB = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int o = sx[k] - base;
+      const int o1 = (sx[k] + 1 < S.w ? sx[k] + 1 : S.w - 1) - base;
+      selA |= (uint32_t)o << (8 * k);
+      selB |= (uint32_t)o1 << (8 * k);
+    }
+    const uint32_t p0a = __builtin_amdgcn_perm(r0hi, r0lo, selA), p0b = __builtin_amdgcn_perm(r0hi, r0lo, selB);
+    const uint32_t p1a = __builtin_amdgcn_perm(r1hi, r1lo, selA), p1b = __builtin_amdgcn_perm(r1hi, r1lo, selB);
+    packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int wa0 = (int)(ab[k] & 0xffff), wa1 = (int)(ab[k] >> 16);
+      const int p00 = (int)((p0a >> (8 * k)) & 0xff), p01 = (int)((p0b >> (8 * k)) & 0xff);
+      const int p10 = (int)((p1a >> (8 * k)) & 0xff), p11 = (int)((p1b >> (8 * k)) & 0xff);
+      const int h0 = __mul24(p00, wa0) + __mul24(p01, wa1);
+      const int h1 = __mul24(p10, wa0) + __mul24(p11, wa1);
+      const int ov = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
+      packed |= (uint32_t)(ov < 0 ? 0 : (ov > 255 ? 255 : ov)) << (8 * k);
+    }
+  }
+  *(uint32_t*)dst = packed;
+}
+
+// interior rows: padded columns [0, 20) and [20 + 4 G, roundup4(w + 38)); one thread per 4 columns
+__global__ __launch_bounds__(256) void k_pyr_edges(const LevelGeom L, const LevelGeom S, size_t pyr_frame_bytes, int level,
+                                                   const uint8_t* __restrict__ src0, int src_stride, size_t src_frame_stride,
+                                                   uint8_t* __restrict__ pyr, int G, int T, unsigned magicT) {
+  const int frame = blockIdx.y;
+  const unsigned e = blockIdx.x * 256 + threadIdx.x;
+  const unsigned Y = __umulhi(e, magicT);        // e / T
+  if (Y >= (unsigned)L.h) return;
+  const int j = (int)(e - Y * (unsigned)T);
+  const int px = j < 5 ? 4 * j : 20 + 4 * G + 4 * (j - 5);
+  const int py = (int)Y + SD_EDGE;
+  const uint32_t v = pyr_px4(L, S, pyr_frame_bytes, level, frame, px, py, src0, src_stride, src_frame_stride, pyr);
+  *(uint32_t*)(pyr + (size_t)frame * pyr_frame_bytes + L.off + (size_t)py * L.pstride + px) = v;
+}
+
+// top / bottom REFLECT_101 border rows: row py copies interior row reflect101(py - 19)
+__global__ __launch_bounds__(256) void k_pyr_rows(const LevelGeom L, size_t pyr_frame_bytes, uint8_t* __restrict__ pyr, int wpr /* dwords per row */,
+                                                  unsigned magicW) {
+  const int frame = blockIdx.y;
+  const unsigned e = blockIdx.x * 256 + threadIdx.x;
+  const unsigned r = __umulhi(e, magicW);        // e / wpr : 0 .. 2 * 19 - 1
+  if (r >= 2u * SD_EDGE) return;
+  const int wc = (int)(e - r * (unsigned)wpr);
+  const int py = r < SD_EDGE ? (int)r : L.h + (int)r;   // 0..18, then h+19 .. h+37
+  const int sy = reflect101(py - SD_EDGE, L.h) + SD_EDGE;
+  uint32_t* base = (uint32_t*)(pyr + (size_t)frame * pyr_frame_bytes + L.off);
+  base[(size_t)py * (L.pstride >> 2) + wc] = base[(size_t)sy * (L.pstride >> 2) + wc];
+}
+
+// ------------------------------------------------------------------------------------------
 // k_fast_cells: one workgroup per (grid cell, frame).  cv::FAST(cellImage, kps, th, true):
 // corner test (>= 9 contiguous ring pixels brighter than v+t or darker than v-t), score =
 // max over the 16 nine-arcs of min |v - p| minus 1, strict-greater 3x3 NMS in which pixels
@@ -967,11 +1079,26 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   const bool prof = h->profiling;
   hipEvent_t* ev = h->ev[h->ev_calls % sd_orb::kRing];
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[0], s));
+  const bool src_aligned = (((uintptr_t)d_imgs | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) == 0;
   for (int l = 0; l < P.nlevels; l++) {
     const LevelGeom& L = P.lv[l];
-    dim3 grid((L.pstride + 255) / 256, (L.prows + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), n), block(64, 4, 1);
-    hipLaunchKernelGGL(k_pyr_level, grid, block, 0, s, L, P.lv[l > 0 ? l - 1 : 0], (size_t)P.pyr_frame_bytes, l, d_imgs, stride,
-                       frame_stride, h->d_pyr);
+    const LevelGeom& S = P.lv[l > 0 ? l - 1 : 0];
+    const bool split = L.w >= 16 && (l == 0 ? src_aligned : L.fast_resize != 0);
+    if (!split) {   // generic single-pass kernel (exact-2x INTER_AREA levels, odd source alignment, tiny levels)
+      dim3 grid((L.pstride + 255) / 256, (L.prows + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), n), block(64, 4, 1);
+      hipLaunchKernelGGL(k_pyr_level, grid, block, 0, s, L, S, (size_t)P.pyr_frame_bytes, l, d_imgs, stride, frame_stride, h->d_pyr);
+      continue;
+    }
+    auto magic = [](unsigned d) { return (unsigned)(0xFFFFFFFFull / d) + 1u; };   // e / d == umulhi(e, magic) for e < 2^31 / d
+    const int G = (L.w - 1) / 4;
+    const int T = 5 + (((L.w + 2 * SD_EDGE + 3) & ~3) - 20 - 4 * G) / 4;
+    const int wpr = ((L.w + 2 * SD_EDGE + 3) & ~3) / 4;
+    hipLaunchKernelGGL(k_pyr_resize, dim3((unsigned)(((size_t)L.h * G + 255) / 256), n), dim3(256), 0, s, L, S, (size_t)P.pyr_frame_bytes,
+                       l, h->d_coef, d_imgs, stride, frame_stride, h->d_pyr, G, magic((unsigned)G));
+    hipLaunchKernelGGL(k_pyr_edges, dim3((unsigned)(((size_t)L.h * T + 255) / 256), n), dim3(256), 0, s, L, S, (size_t)P.pyr_frame_bytes,
+                       l, d_imgs, stride, frame_stride, h->d_pyr, G, T, magic((unsigned)T));
+    hipLaunchKernelGGL(k_pyr_rows, dim3((unsigned)((2 * SD_EDGE * wpr + 255) / 256), n), dim3(256), 0, s, L, (size_t)P.pyr_frame_bytes,
+                       h->d_pyr, wpr, magic((unsigned)wpr));
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], s));
   // blur on the auxiliary stream, beside FAST + selection

@@ -106,6 +106,7 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
 
     // resize tables (level l from level l-1)
     L.area2x2 = 0;
+    L.fast_resize = 0;
     L.cx = L.cy = 0;
     L.scale_x = L.scale_y = 1.0;
     if (l > 0) {
@@ -127,6 +128,15 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
         L.cy = (int)hp.coef.size();
         hp.coef.insert(hp.coef.end(), yo.begin(), yo.end());
         hp.coef.insert(hp.coef.end(), yb.begin(), yb.end());
+        // k_pyr_resize gathers the sources of 4 adjacent outputs out of 8 consecutive source bytes
+        bool ok = L.w >= 8;
+        for (int x0 = 1; ok && x0 + 3 < L.w; x0 += 4)
+          if (std::min(xo[x0 + 3] + 1, S.w - 1) - xo[x0] > 7 || xo[x0 + 3] < xo[x0]) ok = false;
+        for (int x = 0; ok && x < L.w; x++)
+          if ((xa[x] & 0xffff) > 2048 || ((uint32_t)xa[x] >> 16) > 2048) ok = false;
+        for (int y = 0; ok && y < L.h; y++)
+          if (yo[y] < 0 || (yb[y] & 0xffff) > 2048 || ((uint32_t)yb[y] >> 16) > 2048) ok = false;
+        L.fast_resize = ok ? 1 : 0;
       }
     }
 
