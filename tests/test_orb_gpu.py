@@ -102,6 +102,23 @@ def test_edge_inputs(sd, oracle):
     ext.close()
 
 
+@pytest.mark.parametrize("shape,cfg", [((479, 637), (1000, 1.2, 8, 20)), ((242, 321), (500, 1.2, 6, 20)),
+                                       ((480, 640), (1000, 2.0, 4, 20)), ((360, 486), (800, 1.5, 5, 12))])
+def test_odd_geometries_all_stages(sd, oracle, shape, cfg):
+    """Odd widths / byte-unaligned rows (generic level-0 path), exact-2x levels (INTER_AREA fast path), a 1.5x
+    pyramid: every stage compared with the oracle (padded pyramid levels, FAST counts, selected keys, blur)."""
+    H, W = shape
+    ext = sd.ORBextractor(*cfg, W, H, 2)
+    ora = oracle.OrbOracle(*cfg)
+    imgs = np.stack([np.ascontiguousarray(make_image(40 + i, max(W, 640), max(H, 480))[:H, :W]) for i in range(2)])
+    kps, desc, n = ext.extract_batch(imgs)
+    for i in range(2):
+        ok, od = _compare_frame(oracle, ext, ora, imgs[i], i, cfg[2])
+        assert n[i] == len(ok)
+        assert np.array_equal(kps[i, :n[i]], ok) and np.array_equal(desc[i, :n[i]], od)
+    ext.close()
+
+
 def test_errors_are_loud(sd):
     ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 1)
     with pytest.raises(sd.SdError):
