@@ -366,6 +366,11 @@ int sd_debug_sel_prof(unsigned long long* out64, int reset) {
   return read_sel_prof(out64, reset);
 }
 
+int sd_debug_align_prof(unsigned long long* out16, int reset) {
+  SD_REQUIRE(out16, SD_ERR_INVALID_ARG, "null output");
+  return read_align_prof(out16, reset);
+}
+
 int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy, double* R9, double* t3,
                   double* reproj_err) {
   SD_REQUIRE(n >= 4 && Xw && uv && R9 && t3, SD_ERR_INVALID_ARG, "bad arguments");

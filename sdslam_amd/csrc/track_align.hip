@@ -25,6 +25,20 @@
 
 namespace sd {
 
+#ifdef SD_PNP_PROF   // phase timers (tools/prof_pnp.py prints them): cycles of thread 0, summed over frames
+__device__ unsigned long long g_align_prof[16];
+#define APROF_DECL long long _pt = clock64()
+#define APROF(i)                                                                               \
+  do {                                                                                         \
+    long long _n = clock64();                                                                  \
+    if (threadIdx.x == 0) atomicAdd(&g_align_prof[i], (unsigned long long)(_n - _pt));         \
+    _pt = _n;                                                                                  \
+  } while (0)
+#else
+#define APROF_DECL
+#define APROF(i)
+#endif
+
 #define AL_MAXP 300
 #define AL_SLOTS 19   // ceil(300*16 / 256)
 
@@ -153,7 +167,7 @@ __device__ void se3_exp(const double* update, double* res) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr_cur,
+__global__ __launch_bounds__(256, 4) void k_align(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr_cur,
                                                const uint8_t* __restrict__ pyr_ref, TrackBuffers tb, TrackCam cam,
                                                const float* __restrict__ inv_sf, const float* __restrict__ sf, int mode) {
   __shared__ double s_pts[AL_MAXP * 3];
@@ -172,6 +186,7 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
   const int n_last = min(tb.n_last[f], M);
   const int max_pts = (mode == 2 || mode == 3) ? 100 : 300;
 
+  APROF_DECL;
   // ---- gather the first max_pts valid world points, in index order (src/ImageAlign.cc:62-72)
   int running = 0;
   for (int base = 0; base < n_last && running < max_pts; base += 256) {
@@ -246,6 +261,7 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
   for (int k = 0; k < AL_SLOTS; k++) r_patch[k] = r_dx[k] = r_dy[k] = 0.f;
   unsigned jvalid = 0;
 
+  APROF(0);
   const int lvl_hi = 4, lvl_lo = (mode == 3) ? 4 : 2;
   for (int level = lvl_hi; level >= lvl_lo; level--) {
     const LevelGeom L = P->lv[level];
@@ -305,12 +321,14 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
           }
         }
       }
+      APROF(1);
       if (tid == 0) {
         double pose[16];
         m4_mul(s_se3, s_last, pose);
         for (int i = 0; i < 16; i++) s_pose[i] = pose[i];
       }
       __syncthreads();
+      APROF(2);
       // ------------------------------------------------ ComputeResiduals
       double H[21], Jr[6];
 #pragma unroll
@@ -372,6 +390,7 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
         }
         if (p < AL_MAXP * 16) s_chi[p] = chi;
       }
+      APROF(3);
       // fixed-shape reduction of the 27 sums + measurement count
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
@@ -387,6 +406,7 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
         s_cnt[wave] = nmeas;
       }
       __syncthreads();
+      APROF(4);
       // ------------------------------------------------ Optimize (serial part)
       if (tid == 0) {
         iters[level] = it + 1;
@@ -412,6 +432,7 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
           chi2f += v.z;
           chi2f += v.w;
         }
+        APROF(5);
         const double new_chi2 = (double)(chi2f / (float)n_meas);   // float/size_t -> float, then widened
         if (n_meas == 0) stop_ = true;
         ldlt_solve6(s_H, s_b, s_x);
@@ -438,8 +459,10 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
           if (error_ <= 1e-10 || small) brk = 1;
         }
         s_ctrl[0] = brk;
+        APROF(6);
       }
       __syncthreads();
+      APROF(7);
       if (s_ctrl[0]) break;
     }
     // fast mode: "High error in max level means frames are not close, skip other levels"
@@ -466,6 +489,21 @@ __global__ __launch_bounds__(256) void k_align(const OrbPlan* __restrict__ P, co
     tb.al_chi2[f] = chi2_;
     for (int l = 0; l < 16; l++) tb.al_iters[(size_t)f * 16 + l] = iters[l];
   }
+}
+
+int read_align_prof(unsigned long long* out16, int reset) {
+#ifdef SD_PNP_PROF
+  SD_HIP_CHECK(hipDeviceSynchronize());
+  SD_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_align_prof), 16 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[16] = {};
+    SD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_align_prof), z, sizeof(z)));
+  }
+  return SD_OK;
+#else
+  set_error("library built without -DSD_PNP_PROF");
+  return SD_ERR_INVALID_ARG;
+#endif
 }
 
 int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sf,

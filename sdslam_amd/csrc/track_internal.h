@@ -66,6 +66,7 @@ int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const Tr
                              int stride_elems, size_t frame_stride_elems, int n_frames, hipStream_t s);
 int read_pnp_prof(unsigned long long* out32, int reset);
 int read_sel_prof(unsigned long long* out64, int reset);
+int read_align_prof(unsigned long long* out16, int reset);
 int launch_pnp(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sigma2, const PnpParams& pp,
                int n_frames, hipStream_t s);
 

@@ -40,6 +40,20 @@ def run():
     trk.pnp(B, P["probability"], P["min_inliers"], P["max_iterations"], P["min_set"], P["epsilon"], P["th2"], P["max_iterations"])
 
 
+aout = (C.c_ulonglong * 16)()
+L.sd_debug_align_prof(aout, 1)
+for _ in range(3):
+    trk.align(B, 0)
+L.sd_debug_align_prof(aout, 1)
+av = np.array(list(aout), np.float64) / (B * 3)
+an = ["gather+init", "precompute patches", "pose (tid0) + barrier", "residuals+J", "reduce + barrier", "serial: H + float chi2 sum",
+      "serial: LDLT + exp + update", "barrier"]
+print("k_align phases (cycles of thread 0 per frame)")
+for i, nme in enumerate(an):
+    print(f"  {nme:30s} {av[i]:12.0f}")
+print(f"  {'total':30s} {av[:8].sum():12.0f}   iterations {trk.get_align(0, B)['iters'][:, :8].sum(axis=1).mean():.2f}")
+trk.match(B, 8.0, True, True)
+
 run()
 assert L.sd_debug_pnp_prof(out, 1) == 0, "library built without -DSD_PNP_PROF"
 reps = 3
