@@ -4,7 +4,7 @@
 // Replaces SD_SLAM::ImageAlign::ComputePose / Optimize / ComputeResiduals / PrecomputePatches
 // (reference src/ImageAlign.cc:45-421) and Exp/RotationExp (:473-517).
 //
-// Work split (256 threads, <= 300 points x 16 patch pixels = 4800 pixel slots, 19 per thread):
+// Work split (AL_THREADS threads, <= 300 points x 16 patch pixels = 4800 pixel slots, AL_SLOTS per thread):
 //   * each thread keeps its pixels' reference patch value and image gradient (dx, dy) in
 //     registers for the whole level -- the reference's 230 KB fp64 jacobian_cache_ is never
 //     materialised: J = (dx*Jrow0 + dy*Jrow1)*(fx*scale) is recomputed from the point's
@@ -40,7 +40,9 @@ __device__ unsigned long long g_align_prof[16];
 #endif
 
 #define AL_MAXP 300
-#define AL_SLOTS 19   // ceil(300*16 / 256)
+#define AL_THREADS 256
+#define AL_WAVES (AL_THREADS / 64)
+#define AL_SLOTS ((AL_MAXP * 16 + AL_THREADS - 1) / AL_THREADS)   // pixel slots per thread
 
 struct Mat4 { double m[4][4]; };
 
@@ -167,17 +169,17 @@ __device__ void se3_exp(const double* update, double* res) {
   }
 }
 
-__global__ __launch_bounds__(256, 4) void k_align(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr_cur,
+__global__ __launch_bounds__(AL_THREADS, 4) void k_align(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr_cur,
                                                const uint8_t* __restrict__ pyr_ref, TrackBuffers tb, TrackCam cam,
                                                const float* __restrict__ inv_sf, const float* __restrict__ sf, int mode) {
   __shared__ double s_pts[AL_MAXP * 3];
   __shared__ double s_xyz[AL_MAXP * 3];
   __shared__ uint8_t s_vis[AL_MAXP + 4];
   __shared__ __attribute__((aligned(16))) float s_chi[AL_MAXP * 16];
-  __shared__ double s_red[4][28];
+  __shared__ double s_red[AL_WAVES][28];
   __shared__ double s_last[16], s_se3[16], s_pose[16], s_bk[16];
   __shared__ double s_H[36], s_b[6], s_x[6];
-  __shared__ int s_cnt[4];
+  __shared__ int s_cnt[AL_WAVES];
   __shared__ int s_ctrl[4];   // [0] break flag, [1] npts
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = tb.max_points;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, 4) void k_align(const OrbPlan* __restrict__ P,
   APROF_DECL;
   // ---- gather the first max_pts valid world points, in index order (src/ImageAlign.cc:62-72)
   int running = 0;
-  for (int base = 0; base < n_last && running < max_pts; base += 256) {
+  for (int base = 0; base < n_last && running < max_pts; base += AL_THREADS) {
     int i = base + tid;
     bool fl = i < n_last && valid[i] != 0;
     unsigned long long m = __ballot(fl);
@@ -203,11 +205,11 @@ __global__ __launch_bounds__(256, 4) void k_align(const OrbPlan* __restrict__ P,
       s_pts[pos * 3 + 1] = Xw[(size_t)i * 3 + 1];
       s_pts[pos * 3 + 2] = Xw[(size_t)i * 3 + 2];
     }
-    running += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    for (int w = 0; w < AL_WAVES; w++) running += s_cnt[w];
     __syncthreads();
   }
   const int npts = min(running, max_pts);
-  for (int i = tid; i < AL_MAXP; i += 256) s_vis[i] = 0;
+  for (int i = tid; i < AL_MAXP; i += AL_THREADS) s_vis[i] = 0;
 
   double* out_T = tb.Tcur + (size_t)f * 16;
   const double* prior_T = tb.Tprior + (size_t)f * 16;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256, 4) void k_align(const OrbPlan* __restrict__ P,
       if (it == 0) {
 #pragma unroll
         for (int k = 0; k < AL_SLOTS; k++) {
-          const int p = tid + 256 * k;
+          const int p = tid + AL_THREADS * k;
           const int pt = p >> 4, pix = p & 15;
           if (pt < npts) {
             const double p0 = s_pts[pt * 3], p1 = s_pts[pt * 3 + 1], p2 = s_pts[pt * 3 + 2];
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256, 4) void k_align(const OrbPlan* __restrict__ P,
       int nmeas = 0;
 #pragma unroll
       for (int k = 0; k < AL_SLOTS; k++) {
-        const int p = tid + 256 * k;
+        const int p = tid + AL_THREADS * k;
         const int pt = p >> 4, pix = p & 15;
         float chi = 0.f;
         if (pt < npts && s_vis[pt]) {
@@ -413,13 +415,19 @@ __global__ __launch_bounds__(256, 4) void k_align(const OrbPlan* __restrict__ P,
         int q = 0;
         for (int a = 0; a < 6; a++)
           for (int bb = a; bb < 6; bb++) {
-            double v = ((s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]));
+            double v = s_red[0][q];
+            for (int w = 1; w < AL_WAVES; w++) v += s_red[w][q];
             s_H[a * 6 + bb] = v;
             s_H[bb * 6 + a] = v;
             q++;
           }
-        for (int a = 0; a < 6; a++) s_b[a] = ((s_red[0][21 + a] + s_red[1][21 + a]) + (s_red[2][21 + a] + s_red[3][21 + a]));
-        const int n_meas = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        for (int a = 0; a < 6; a++) {
+          double v = s_red[0][21 + a];
+          for (int w = 1; w < AL_WAVES; w++) v += s_red[w][21 + a];
+          s_b[a] = v;
+        }
+        int n_meas = 0;
+        for (int w = 0; w < AL_WAVES; w++) n_meas += s_cnt[w];
         // float chi2 in the reference's order; 16-byte LDS reads are issued ahead of the dependent adds
         float chi2f = 0.0f;
         const float4* c4 = (const float4*)s_chi;
@@ -508,7 +516,7 @@ int read_align_prof(unsigned long long* out16, int reset) {
 
 int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sf,
                  const float* d_sf, int n_frames, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_align, dim3(n_frames), dim3(256), 0, s, cur->d_plan, cur->d_pyr, ref->d_pyr, tb, cam, d_inv_sf, d_sf, mode);
+  hipLaunchKernelGGL(k_align, dim3(n_frames), dim3(AL_THREADS), 0, s, cur->d_plan, cur->d_pyr, ref->d_pyr, tb, cam, d_inv_sf, d_sf, mode);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }
