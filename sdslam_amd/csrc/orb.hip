@@ -1023,12 +1023,31 @@ using namespace sd;
 static const char* kStageNames[ST_COUNT] = {"pyramid", "fast_nms", "select", "blur", "orient_desc"};
 
 static int free_geom(sd_orb* h) {
-  void* ptrs[] = {h->d_cells, h->d_tiles, h->d_coef, h->d_pyr, h->d_blur, h->d_cand, h->d_scratch,
+  void* ptrs[] = {h->d_cells, h->d_tiles, h->d_coef, h->pyr_set[0], h->pyr_set[1], h->d_blur, h->d_cand, h->d_scratch,
                   h->d_cell_count, h->d_sel, h->d_sel_count};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  h->pyr_set[0] = h->pyr_set[1] = nullptr;
   h->d_cells = nullptr; h->d_tiles = nullptr; h->d_coef = nullptr; h->d_pyr = nullptr; h->d_blur = nullptr;
   h->d_cand = nullptr; h->d_scratch = nullptr; h->d_cell_count = nullptr; h->d_sel = nullptr; h->d_sel_count = nullptr;
+  return SD_OK;
+}
+
+static void select_set(sd_orb* h, int sidx) {
+  h->set = sidx;
+  h->d_pyr = h->pyr_set[sidx];
+  h->d_kps = h->kps_set[sidx];
+  h->d_kps_un = h->kps_un_set[sidx];
+  h->d_desc = h->desc_set[sidx];
+  h->d_nout = h->nout_set[sidx];
+}
+
+static int wait_trackers(sd_orb* h) {   // host-side: nothing may still read any output set
+  for (int i = 0; i < 2; i++)
+    if (h->set_busy[i]) {
+      SD_HIP_CHECK(hipEventSynchronize(h->ev_set_free[i]));
+      h->set_busy[i] = false;
+    }
   return SD_OK;
 }
 
@@ -1043,6 +1062,7 @@ static int ensure_geometry(sd_orb* h, int w, int hgt) {
   SD_REQUIRE(h->hp.max_cells_per_level <= SEL_MAX_CELLS, SD_ERR_INVALID_ARG, "too many grid cells per level");
   SD_HIP_CHECK(hipSetDevice(h->device));
   SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  { int rcw = wait_trackers(h); if (rcw != SD_OK) return rcw; }
   free_geom(h);
   const HostPlan& hp = h->hp;
   const size_t B = h->max_batch;
@@ -1050,14 +1070,17 @@ static int ensure_geometry(sd_orb* h, int w, int hgt) {
   SD_HIP_CHECK(hipMalloc(&h->d_cells, std::max<size_t>(hp.cells.size(), 1) * sizeof(CellGeom)));
   SD_HIP_CHECK(hipMalloc(&h->d_tiles, std::max<size_t>(hp.blur_tiles.size(), 1) * sizeof(BlurTile)));
   SD_HIP_CHECK(hipMalloc(&h->d_coef, hp.coef.size() * sizeof(int32_t)));
-  SD_HIP_CHECK(hipMalloc(&h->d_pyr, hp.plan.pyr_frame_bytes * B + slack));
+  for (int i = 0; i < h->nsets; i++) {
+    SD_HIP_CHECK(hipMalloc(&h->pyr_set[i], hp.plan.pyr_frame_bytes * B + slack));
+    SD_HIP_CHECK(hipMemsetAsync(h->pyr_set[i], 0, hp.plan.pyr_frame_bytes * B + slack, h->stream));
+  }
+  select_set(h, 0);
   SD_HIP_CHECK(hipMalloc(&h->d_blur, hp.plan.pyr_frame_bytes * B + slack));
   SD_HIP_CHECK(hipMalloc(&h->d_cand, std::max<size_t>(hp.plan.cand_per_frame, 1) * B * 4));
   SD_HIP_CHECK(hipMalloc(&h->d_scratch, std::max<size_t>(hp.plan.cand_per_frame, 1) * B * 4));
   SD_HIP_CHECK(hipMalloc(&h->d_cell_count, std::max<size_t>(hp.plan.ncells, 1) * B * 4));
   SD_HIP_CHECK(hipMalloc(&h->d_sel, std::max<size_t>(hp.plan.nsel, 1) * B * 4));
   SD_HIP_CHECK(hipMalloc(&h->d_sel_count, (size_t)h->nlevels * B * 4));
-  SD_HIP_CHECK(hipMemsetAsync(h->d_pyr, 0, hp.plan.pyr_frame_bytes * B + slack, h->stream));
   SD_HIP_CHECK(hipMemsetAsync(h->d_blur, 0, hp.plan.pyr_frame_bytes * B + slack, h->stream));
   if (!hp.cells.empty())
     SD_HIP_CHECK(hipMemcpyAsync(h->d_cells, hp.cells.data(), hp.cells.size() * sizeof(CellGeom), hipMemcpyHostToDevice, h->stream));
@@ -1078,6 +1101,12 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   hipStream_t s = h->stream;
   const bool prof = h->profiling;
   hipEvent_t* ev = h->ev[h->ev_calls % sd_orb::kRing];
+  // next output set; a tracker may still be reading its previous contents on another stream
+  select_set(h, (h->set + 1) % h->nsets);
+  if (h->set_busy[h->set]) {
+    SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_set_free[h->set], 0));
+    h->set_busy[h->set] = false;
+  }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[0], s));
   const bool src_aligned = (((uintptr_t)d_imgs | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) == 0;
   for (int l = 0; l < P.nlevels; l++) {
@@ -1118,7 +1147,6 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
                      h->d_cell_count, h->d_scratch, h->d_sel, h->d_sel_count);
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[7], s));
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_blur_done, 0));
-  if (h->wait_before_outputs) SD_HIP_CHECK(hipStreamWaitEvent(s, h->wait_before_outputs, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[4], s));
   const int cap = std::max(P.nsel, 1);
   hipLaunchKernelGGL(k_orient_desc, dim3((cap + 3) / 4, n), dim3(256), 0, s, h->d_plan, h->d_pyr, h->d_blur, h->d_sel,
@@ -1130,11 +1158,37 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
     hipLaunchKernelGGL(k_undistort, dim3((cap + 255) / 256, n), dim3(256), 0, s, h->d_kps, h->d_kps_un, h->d_nout, cap, D);
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[5], s));
+  SD_HIP_CHECK(hipEventRecord(h->ev_extract_done, s));
+  h->extract_recorded = true;
   SD_HIP_CHECK(hipGetLastError());
   if (prof) h->ev_calls++;
   h->last_frames = n;
   return SD_OK;
 }
+
+namespace sd {
+// Second output set for a handle whose frames a tracker consumes on its own stream.
+int orb_enable_double_buffer(sd_orb* h) {
+  if (h->nsets == 2) return SD_OK;
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  int nsel = 0;
+  for (int q : h->hp.quota) nsel += q;
+  const size_t cap = std::max(nsel, 1), B = h->max_batch;
+  SD_HIP_CHECK(hipMalloc(&h->kps_set[1], cap * B * sizeof(sd_keypoint)));
+  SD_HIP_CHECK(hipMalloc(&h->kps_un_set[1], cap * B * sizeof(sd_keypoint)));
+  SD_HIP_CHECK(hipMalloc(&h->desc_set[1], cap * B * 32));
+  SD_HIP_CHECK(hipMalloc(&h->nout_set[1], B * 4));
+  SD_HIP_CHECK(hipMemset(h->nout_set[1], 0, B * 4));
+  if (h->have_geom) {
+    const size_t bytes = h->hp.plan.pyr_frame_bytes * B + 4096;
+    SD_HIP_CHECK(hipMalloc(&h->pyr_set[1], bytes));
+    SD_HIP_CHECK(hipMemset(h->pyr_set[1], 0, bytes));
+  }
+  h->nsets = 2;
+  return SD_OK;
+}
+}  // namespace sd
 
 namespace sd {
 int read_sel_prof(unsigned long long* out64, int reset) {   // [0..55] select [level][slot<7], [56..63] FAST phases
@@ -1199,10 +1253,14 @@ int sd_orb_create(int nfeatures, float scale_factor, int nlevels, int th_fast, i
   hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&h->d_plan, sizeof(OrbPlan));
   if (e == hipSuccess) e = hipMalloc(&h->d_img, (size_t)max_w * max_h * max_batch);
-  if (e == hipSuccess) e = hipMalloc(&h->d_kps, cap * max_batch * sizeof(sd_keypoint));
-  if (e == hipSuccess) e = hipMalloc(&h->d_kps_un, cap * max_batch * sizeof(sd_keypoint));
-  if (e == hipSuccess) e = hipMalloc(&h->d_desc, cap * max_batch * 32);
-  if (e == hipSuccess) e = hipMalloc(&h->d_nout, (size_t)max_batch * 4);
+  if (e == hipSuccess) e = hipMalloc(&h->kps_set[0], cap * max_batch * sizeof(sd_keypoint));
+  if (e == hipSuccess) e = hipMalloc(&h->kps_un_set[0], cap * max_batch * sizeof(sd_keypoint));
+  if (e == hipSuccess) e = hipMalloc(&h->desc_set[0], cap * max_batch * 32);
+  if (e == hipSuccess) e = hipMalloc(&h->nout_set[0], (size_t)max_batch * 4);
+  if (e == hipSuccess) e = hipMemset(h->nout_set[0], 0, (size_t)max_batch * 4);
+  for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&h->ev_set_free[i], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_extract_done, hipEventDisableTiming);
+  if (e == hipSuccess) select_set(h, 0);
   for (int r = 0; r < sd_orb::kRing && e == hipSuccess; r++)
     for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
@@ -1222,10 +1280,15 @@ void sd_orb_destroy(sd_orb* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)wait_trackers(h);
   free_geom(h);
-  void* ptrs[] = {h->d_plan, h->d_img, h->d_kps, h->d_kps_un, h->d_desc, h->d_nout};
+  void* ptrs[] = {h->d_plan, h->d_img, h->kps_set[0], h->kps_set[1], h->kps_un_set[0], h->kps_un_set[1], h->desc_set[0],
+                  h->desc_set[1], h->nout_set[0], h->nout_set[1]};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (int i = 0; i < 2; i++)
+    if (h->ev_set_free[i]) (void)hipEventDestroy(h->ev_set_free[i]);
+  if (h->ev_extract_done) (void)hipEventDestroy(h->ev_extract_done);
   for (int r = 0; r < sd_orb::kRing; r++)
     for (int i = 0; i < 8; i++)
       if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);

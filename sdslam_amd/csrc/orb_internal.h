@@ -19,9 +19,22 @@ struct sd_orb {
   // blur depends only on the pyramid: it runs on aux_stream beside FAST + selection
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_pyr_done = nullptr, ev_blur_done = nullptr, ev_blur_start = nullptr;
-  // set by a tracker: the previous step's PnP still reads this handle's keypoints, so the kernel
-  // that overwrites them (k_orient_desc) waits for it
-  hipEvent_t wait_before_outputs = nullptr;
+  // Output sets.  What a tracker reads (padded pyramid, keypoints, descriptors, counts) exists once
+  // or -- after sd::orb_enable_double_buffer, which sd_track_create calls on its `cur` handle -- twice:
+  // extraction alternates between the sets, so batch n+1 is extracted on `stream` while the tracker
+  // still works on batch n on its own stream.  d_pyr / d_kps / d_kps_un / d_desc / d_nout below always
+  // alias the set of the most recent extraction.  A tracker records ev_set_free[set] after every
+  // kernel that reads a set; the extraction that is about to overwrite that set waits for it.
+  int nsets = 1, set = 0;
+  uint8_t* pyr_set[2] = {nullptr, nullptr};
+  sd_keypoint* kps_set[2] = {nullptr, nullptr};
+  sd_keypoint* kps_un_set[2] = {nullptr, nullptr};
+  uint8_t* desc_set[2] = {nullptr, nullptr};
+  int32_t* nout_set[2] = {nullptr, nullptr};
+  hipEvent_t ev_set_free[2] = {nullptr, nullptr};
+  bool set_busy[2] = {false, false};
+  hipEvent_t ev_extract_done = nullptr;   // end of the most recent extraction on `stream`
+  bool extract_recorded = false;
   // device buffers
   sd::OrbPlan* d_plan = nullptr;
   sd::CellGeom* d_cells = nullptr;
@@ -51,3 +64,6 @@ struct sd_orb {
   int ev_calls = 0;   // calls recorded since profiling was (re-)enabled
 };
 
+namespace sd {
+int orb_enable_double_buffer(sd_orb* h);   // orb.hip; idempotent
+}

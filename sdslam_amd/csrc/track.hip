@@ -30,11 +30,11 @@ struct sd_track {
   float* d_inv_sf = nullptr;
   float* d_sigma2 = nullptr;
   std::vector<void*> allocs;
-  // PnP is latency-bound (one wavefront per frame): it runs on its own stream so that the next
-  // batch's pyramid / FAST / selection overlap it; the kernel that overwrites the keypoints it
-  // reads (k_orient_desc of the next extraction on `cur`) waits for ev_pnp_done.
+  // The tracking kernels (align, match, PnP: latency-bound, few waves) run on their own stream, so
+  // the extraction of the next batch on cur->stream overlaps them; `cur` is double-buffered
+  // (orb_internal.h: output sets) and every tracking launch waits for the extraction it consumes
+  // (ev_extract_done) and marks the sets it read (ev_set_free).
   hipStream_t pnp_stream = nullptr;
-  hipEvent_t ev_match_done = nullptr, ev_pnp_done = nullptr;
   bool profiling = false;
   static const int kRing = 128;
   hipEvent_t ev[kRing][6] = {};
@@ -120,13 +120,18 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
     if (e == hipSuccess) e = hipMemcpy(h->d_sigma2, cur->hp.sigma2.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
     for (int r = 0; r < sd_track::kRing && e == hipSuccess; r++)
       for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->pnp_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_match_done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_pnp_done, hipEventDisableTiming);
+    if (e == hipSuccess) {
+      // highest priority: the few, long-running tracking workgroups should take their slots as soon as
+      // they are free and leave the rest of the machine to the extraction kernels of the next batch
+      int lo = 0, hi = 0;
+      e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->pnp_stream, hipStreamNonBlocking, hi);
+    }
     if (e != hipSuccess) {
       set_error(std::string("sd_track_create: ") + hipGetErrorString(e));
       rc = SD_ERR_HIP;
     }
+    if (rc == SD_OK) rc = orb_enable_double_buffer(cur);
   }
   if (rc != SD_OK) {
     sd_track_destroy(h);
@@ -141,10 +146,7 @@ void sd_track_destroy(sd_track* h) {
   (void)hipSetDevice(h->device);
   if (h->pnp_stream) (void)hipStreamSynchronize(h->pnp_stream);
   if (h->cur && h->cur->stream) (void)hipStreamSynchronize(h->cur->stream);
-  if (h->cur && h->cur->wait_before_outputs == h->ev_pnp_done) h->cur->wait_before_outputs = nullptr;
   if (h->pnp_stream) (void)hipStreamDestroy(h->pnp_stream);
-  if (h->ev_match_done) (void)hipEventDestroy(h->ev_match_done);
-  if (h->ev_pnp_done) (void)hipEventDestroy(h->ev_pnp_done);
   for (void* p : h->allocs) (void)hipFree(p);
   for (int r = 0; r < sd_track::kRing; r++)
     for (int i = 0; i < 6; i++)
@@ -211,6 +213,25 @@ int sd_track_set_rand(sd_track* h, int frame0, int n_frames, const int32_t* rand
   return SD_OK;
 }
 
+// Order the tracking stream behind the extractions it consumes ...
+static int wait_inputs(sd_track* h, bool need_ref) {
+  if (h->cur->extract_recorded) SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, h->cur->ev_extract_done, 0));
+  if (need_ref && h->ref->extract_recorded) SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, h->ref->ev_extract_done, 0));
+  return SD_OK;
+}
+// ... and tell the extractors which output sets the kernel just queued is reading.
+static int mark_reads(sd_track* h, bool used_ref) {
+  sd_orb* c = h->cur;
+  SD_HIP_CHECK(hipEventRecord(c->ev_set_free[c->set], h->pnp_stream));
+  c->set_busy[c->set] = true;
+  if (used_ref && h->ref != h->cur) {
+    sd_orb* r = h->ref;
+    SD_HIP_CHECK(hipEventRecord(r->ev_set_free[r->set], h->pnp_stream));
+    r->set_busy[r->set] = true;
+  }
+  return SD_OK;
+}
+
 static int check_ready(sd_track* h, int n_frames) {
   SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
   SD_REQUIRE(h->have_cam, SD_ERR_INVALID_ARG, "sd_track_set_camera has not been called");
@@ -226,22 +247,28 @@ int sd_track_align(sd_track* h, int n_frames, int mode) {
   SD_REQUIRE(mode >= 0 && mode <= 3, SD_ERR_INVALID_ARG, "bad mode");
   SD_REQUIRE(h->ref->have_geom && h->ref->last_frames >= n_frames && h->ref->cur_w == h->cur->cur_w && h->ref->cur_h == h->cur->cur_h,
              SD_ERR_INVALID_ARG, "reference frames not extracted or of different size");
-  hipStream_t s = h->cur->stream;
+  hipStream_t s = h->pnp_stream;
+  rc = wait_inputs(h, true);
+  if (rc != SD_OK) return rc;
   hipEvent_t* ev = h->ev[h->ev_calls[0] % sd_track::kRing];
   if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[0], s));
   rc = launch_align(h->cur, h->ref, h->tb, h->cam, h->d_inv_sf, h->d_sf, n_frames, mode, s);
   if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[1], s)); h->ev_calls[0]++; }
+  if (rc == SD_OK) rc = mark_reads(h, true);
   return rc;
 }
 
 int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori) {
   int rc = check_ready(h, n_frames);
   if (rc != SD_OK) return rc;
-  hipStream_t s = h->cur->stream;
+  hipStream_t s = h->pnp_stream;
+  rc = wait_inputs(h, false);
+  if (rc != SD_OK) return rc;
   hipEvent_t* ev = h->ev[h->ev_calls[1] % sd_track::kRing];
   if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[2], s));
   rc = launch_match(h->cur, h->tb, h->cam, h->d_sf, n_frames, th, mono, check_ori, s);
   if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[3], s)); h->ev_calls[1]++; }
+  if (rc == SD_OK) rc = mark_reads(h, false);
   return rc;
 }
 
@@ -260,6 +287,7 @@ int sd_track_stereo_from_depth(sd_track* h, int n_frames, const float* depth, in
   int rc = check_ready(h, n_frames);
   if (rc != SD_OK) return rc;
   SD_REQUIRE(depth && w >= 1 && hgt >= 1 && stride_elems >= w, SD_ERR_INVALID_ARG, "bad depth image");
+  SD_HIP_CHECK(hipStreamSynchronize(h->pnp_stream));   // a queued match may still read the stereo arrays
   float* d_depth = nullptr;
   const size_t total = (size_t)n_frames * w * hgt;
   SD_HIP_CHECK(hipMalloc(&d_depth, total * 4));
@@ -305,14 +333,13 @@ int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers,
   pp.n_iterations = n_iterations;
   pp.rand_per_frame = h->rand_per_frame;
   hipStream_t s = h->pnp_stream;
-  SD_HIP_CHECK(hipEventRecord(h->ev_match_done, h->cur->stream));   // everything queued so far (extract, align, match)
-  SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_match_done, 0));
+  rc = wait_inputs(h, false);
+  if (rc != SD_OK) return rc;
   hipEvent_t* ev = h->ev[h->ev_calls[2] % sd_track::kRing];
   if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[4], s));
   rc = launch_pnp(h->cur, h->tb, h->cam, h->d_sigma2, pp, n_frames, s);
   if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[5], s)); h->ev_calls[2]++; }
-  SD_HIP_CHECK(hipEventRecord(h->ev_pnp_done, s));
-  h->cur->wait_before_outputs = h->ev_pnp_done;   // next k_orient_desc on `cur` overwrites what PnP reads
+  if (rc == SD_OK) rc = mark_reads(h, false);
   return rc;
 }
 
