@@ -424,6 +424,36 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t* __restrict__ c, 
   return max(a, -b) - 1;
 }
 
+// Corner test and cornerScore in one: with A = min over the 16 nine-arcs of max(p) and
+// B = max over the arcs of min(p), a 9-arc darker than v - th exists iff v - A > th, a brighter one iff
+// B - v > th, and cornerScore = max(v - A, B - v) - 1 (the same quantity as fast_corner_score: min / max
+// of the differences d = v - p over an arc are v - max(p) / v - min(p)).  Sliding 9-windows on the ring
+// are built from 3-windows with v_max3 / v_min3: 2 x (16 + 16 + 8) instructions.  Returns the score;
+// the pixel is a corner iff score >= th.
+__device__ __forceinline__ int fast_ring_score(const uint8_t* __restrict__ c, int tp) {
+  int p[16];
+  const int v = c[0];
+  p[0] = c[3 * tp]; p[1] = c[3 * tp + 1]; p[2] = c[2 * tp + 2]; p[3] = c[tp + 3];
+  p[4] = c[3]; p[5] = c[-tp + 3]; p[6] = c[-2 * tp + 2]; p[7] = c[-3 * tp + 1];
+  p[8] = c[-3 * tp]; p[9] = c[-3 * tp - 1]; p[10] = c[-2 * tp - 2]; p[11] = c[-tp - 3];
+  p[12] = c[-3]; p[13] = c[tp - 3]; p[14] = c[2 * tp - 2]; p[15] = c[3 * tp - 1];
+  int x3[16], n3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    x3[k] = max(max(p[k], p[(k + 1) & 15]), p[(k + 2) & 15]);
+    n3[k] = min(min(p[k], p[(k + 1) & 15]), p[(k + 2) & 15]);
+  }
+  int A = 255, B = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int x9 = max(max(x3[k], x3[(k + 3) & 15]), x3[(k + 6) & 15]);
+    const int n9 = min(min(n3[k], n3[(k + 3) & 15]), n3[(k + 6) & 15]);
+    A = min(A, x9);
+    B = max(B, n9);
+  }
+  return max(v - A, B - v) - 1;
+}
+
 #ifdef SD_PNP_PROF   // stage timers of k_fast_cells (tools/prof_select.py --fast): cycles of thread 0 per phase
 __device__ unsigned long long g_fast_prof[8];
 #define FPROF_DECL long long _pt = clock64()
@@ -442,8 +472,9 @@ __device__ unsigned long long g_fast_prof[8];
 //   A. every wave owns a contiguous band of rows; per 64-px row segment a 4-read compass test
 //      (a 9-arc always contains two ADJACENT compass points of the same polarity) rejects most
 //      pixels; survivors are appended, in raster order, to the wave's LDS queue (ballot prefix);
-//   B. the queue is processed densely (all lanes busy): full ring classification; true corners
-//      are re-compacted in place (still raster order) and scored densely in a second pass;
+//   B. the queue is processed densely (all lanes busy): one pass computes cornerScore from sliding
+//      min / max windows on the ring (fast_ring_score); score >= th is the corner test; corners are
+//      re-compacted in place (still raster order) and their scores go to the LDS score map;
 //   C. after a block barrier, NMS on the queued corners against the LDS score map, then ordered
 //      emission (wave bands are contiguous in raster order, so per-wave counts give offsets).
 __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ P,
@@ -532,7 +563,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
       }
     }
     FPROF(1);
-    // ---- B1: full 9-contiguous test on the queued pixels; corners re-compacted in place
+    // ---- B: ring test + score of the queued pixels in one pass (dense); corners re-compacted in place
     int cn = 0;
     for (int e0 = 0; e0 < qn; e0 += 64) {
       const int e = e0 + lane;
@@ -541,7 +572,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
       if (e < qn) {
         q = queue[e];
         const int y = (int)__umulhi(q, magic), x = (int)q - __mul24(y, zw);
-        corner = fast_is_corner(tile + __mul24(y + 3, TP) + x + 3 + sh, TP, th);
+        const int sc_v = fast_ring_score(tile + __mul24(y + 3, TP) + x + 3 + sh, TP);
+        corner = sc_v >= th;
+        if (corner && sc_v > 0) sc[__mul24(y + 1, SP) + x + 1] = (uint8_t)sc_v;
       }
       const unsigned long long m = __ballot(corner);   // all reads of this chunk precede the writes (cn <= e0)
       if (corner) queue[cn + __popcll(m & lt)] = (uint16_t)q;
@@ -549,16 +582,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
     }
     qn = cn;
     FPROF(2);
-    // ---- B2: scores of the corners (dense)
-    for (int e0 = 0; e0 < qn; e0 += 64) {
-      const int e = e0 + lane;
-      if (e < qn) {
-        const unsigned q = queue[e];
-        const int y = (int)__umulhi(q, magic), x = (int)q - __mul24(y, zw);
-        const int s = fast_corner_score(tile + __mul24(y + 3, TP) + x + 3 + sh, TP);
-        if (s > 0) sc[__mul24(y + 1, SP) + x + 1] = (uint8_t)s;
-      }
-    }
     FPROF(3);
     __syncthreads();
     FPROF(4);
