@@ -914,10 +914,17 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
                                                      const uint32_t* __restrict__ sel,
                                                      const int32_t* __restrict__ sel_count,
                                                      sd_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                     int32_t* __restrict__ nout, int cap) {
-  const int frame = blockIdx.y;
+                                                     int32_t* __restrict__ nout, int cap, int n_frames, int bpf) {
+  // XCD-aware block order: workgroups are handed to the 8 XCDs round-robin, and each XCD has its own
+  // 4 MB L2.  Block b works on frame 8 * (b / (8 * bpf)) + (b % 8), so all workgroups of a frame run on
+  // ONE XCD and the frame's two pyramids (2.8 MB at VGA) stay L2-resident while its ~1000 overlapping
+  // 31 x 31 patches are read (measured: HBM fetch 6.1 GB -> see DESIGN.md section 6).
+  const int bx = blockIdx.x;
+  const int xcd = bx & 7, t = bx >> 3;
+  const int frame = (t / bpf) * 8 + xcd, blk = t % bpf;
+  if (frame >= n_frames) return;
   const int lane = threadIdx.x & 63;
-  int g = blockIdx.x * 4 + (threadIdx.x >> 6);   // output slot of this wave
+  int g = blk * 4 + (threadIdx.x >> 6);   // output slot of this wave
   // locate (level, index) from the per-level counts (uniform scalar loop)
   const int32_t* sc = sel_count + (size_t)frame * P->nlevels;
   int level = -1, idx = 0, acc = 0;
@@ -929,7 +936,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
     }
     acc += n;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) nout[frame] = min(acc, cap);
+  if (blk == 0 && threadIdx.x == 0) nout[frame] = min(acc, cap);
   if (level < 0 || g >= cap) return;
   const LevelGeom L = P->lv[level];
   const uint32_t key = sel[(size_t)frame * P->nsel + L.sel_off + idx];
@@ -1172,8 +1179,11 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_blur_done, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[4], s));
   const int cap = std::max(P.nsel, 1);
-  hipLaunchKernelGGL(k_orient_desc, dim3((cap + 3) / 4, n), dim3(256), 0, s, h->d_plan, h->d_pyr, h->d_blur, h->d_sel,
-                     h->d_sel_count, h->d_kps, h->d_desc, h->d_nout, cap);
+  {
+    const int bpf = (cap + 3) / 4;
+    hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)(((n + 7) / 8) * 8 * bpf)), dim3(256), 0, s, h->d_plan, h->d_pyr, h->d_blur,
+                       h->d_sel, h->d_sel_count, h->d_kps, h->d_desc, h->d_nout, cap, n, bpf);
+  }
   if (h->have_dist) {   // mvKeysUn != mvKeys only when k1 != 0 (src/Frame.cc:336-339)
     DistParams D;
     D.fx = h->dist_K[0]; D.fy = h->dist_K[1]; D.cx = h->dist_K[2]; D.cy = h->dist_K[3];
