@@ -81,6 +81,17 @@ class ORBextractor {
   std::vector<float> GetScaleSigmaSquares() { return table(2); }
   std::vector<float> GetInverseScaleSigmaSquares() { return table(3); }
 
+  // Frame::UndistortKeyPoints (src/Frame.cc:335-366): K as Converter::toCvMat(K) (CV_32F), DistCoef {k1,k2,p1,p2,k3}.
+  // After this, matching / PnP read mvKeysUn; UndistortedKeyPoints() returns them for the frames of the last call.
+  void SetDistortion(float fx, float fy, float cx, float cy, float k1, float k2 = 0, float p1 = 0, float p2 = 0, float k3 = 0) {
+    check(sd_orb_set_distortion(h_, fx, fy, cx, cy, k1, k2, p1, p2, k3));
+  }
+  void UndistortedKeyPoints(int frame, std::vector<KeyPoint>& mvKeysUn, int n) {
+    std::vector<KeyPoint> all(cap_);
+    check(sd_orb_download_undistorted(h_, frame, 1, all.data(), cap_));
+    mvKeysUn.assign(all.begin(), all.begin() + (n < cap_ ? n : cap_));
+  }
+
   sd_orb* handle() { return h_; }
 
  private:
@@ -133,6 +144,12 @@ class TrackBatch {
   }
   // LastFrame.GetPose(), CurrentFrame.GetPose() (prior); 16 doubles column-major each
   void SetPoses(int frame, const double* Tlast, const double* Tcur_prior) { check(sd_track_set_poses(h_, frame, 1, Tlast, Tcur_prior)); }
+  // Frame::ComputeStereoFromRGBD (src/Frame.cc:399-417) on the current frames: depth = CV_32F images, one per frame
+  void ComputeStereoFromRGBD(int n_frames, const float* imDepth, int cols, int rows, int step_elems, size_t frame_step_elems) {
+    check(sd_track_stereo_from_depth(h_, n_frames, imDepth, cols, rows, step_elems, frame_step_elems));
+  }
+  // stereo frames: mvuRight computed by the caller (-1 = no match)
+  void SetURight(int frame, const float* mvuRight, int n) { check(sd_track_set_uright(h_, frame, 1, mvuRight, n)); }
   sd_track* handle() { return h_; }
 
  private:
