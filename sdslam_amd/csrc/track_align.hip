@@ -20,6 +20,9 @@
 // padded pyramids the extractor left resident in HBM (levels 4,3,2 only).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "orb_internal.h"
 #include "track_internal.h"
 
@@ -171,7 +174,8 @@ __device__ void se3_exp(const double* update, double* res) {
 
 __global__ __launch_bounds__(AL_THREADS, 4) void k_align(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr_cur,
                                                const uint8_t* __restrict__ pyr_ref, TrackBuffers tb, TrackCam cam,
-                                               const float* __restrict__ inv_sf, const float* __restrict__ sf, int mode) {
+                                               const float* __restrict__ inv_sf, const float* __restrict__ sf, int mode,
+                                               int n_frames) {
   __shared__ double s_pts[AL_MAXP * 3];
   __shared__ double s_xyz[AL_MAXP * 3];
   __shared__ uint8_t s_vis[AL_MAXP + 4];
@@ -181,7 +185,11 @@ __global__ __launch_bounds__(AL_THREADS, 4) void k_align(const OrbPlan* __restri
   __shared__ double s_H[36], s_b[6], s_x[6];
   __shared__ int s_cnt[AL_WAVES];
   __shared__ int s_ctrl[4];   // [0] break flag, [1] npts
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // persistent workgroups: the grid may be smaller than the batch (launch_align), so that the aligner
+  // occupies only part of every CU while the next batch is being extracted beside it
+  for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
+  __syncthreads();   // shared state of the previous frame is dead
   const int M = tb.max_points;
   const uint8_t* valid = tb.valid + (size_t)f * M;
   const double* Xw = tb.Xw + (size_t)f * M * 3;
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(AL_THREADS, 4) void k_align(const OrbPlan* __restri
       tb.al_chi2[f] = 1e10;
       for (int l = 0; l < 16; l++) tb.al_iters[(size_t)f * 16 + l] = 0;
     }
-    return;
+    continue;
   }
   if (tid == 0) {
     // column-major in HBM (Eigen::Matrix4d::data()) -> row-major working copies
@@ -497,6 +505,7 @@ __global__ __launch_bounds__(AL_THREADS, 4) void k_align(const OrbPlan* __restri
     tb.al_chi2[f] = chi2_;
     for (int l = 0; l < 16; l++) tb.al_iters[(size_t)f * 16 + l] = iters[l];
   }
+  }   // frames of this workgroup
 }
 
 int read_align_prof(unsigned long long* out16, int reset) {
@@ -516,7 +525,10 @@ int read_align_prof(unsigned long long* out16, int reset) {
 
 int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sf,
                  const float* d_sf, int n_frames, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_align, dim3(n_frames), dim3(AL_THREADS), 0, s, cur->d_plan, cur->d_pyr, ref->d_pyr, tb, cam, d_inv_sf, d_sf, mode);
+  static const int grid_cap = [] { const char* e = getenv("SD_ALIGN_GRID"); return e ? atoi(e) : 0; }();
+  const int grid = grid_cap > 0 ? std::min(n_frames, grid_cap) : n_frames;
+  hipLaunchKernelGGL(k_align, dim3(grid), dim3(AL_THREADS), 0, s, cur->d_plan, cur->d_pyr, ref->d_pyr, tb, cam, d_inv_sf, d_sf, mode,
+                     n_frames);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }

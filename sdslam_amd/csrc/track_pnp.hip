@@ -15,7 +15,9 @@
 // bases agree with the oracle (hypot is the host libm's, restated in sd_hypot.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 #include "orb_internal.h"
 #include "sd_hypot.h"
@@ -1014,7 +1016,8 @@ __device__ __forceinline__ bool pnp_is_inlier(const double* Rt, const float* q /
 }
 
 __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all,
-                                            TrackBuffers tb, TrackCam tcam, const float* __restrict__ sigma2, PnpParams pp) {
+                                            TrackBuffers tb, TrackCam tcam, const float* __restrict__ sigma2, PnpParams pp,
+                                            int n_frames) {
   // gathered correspondences live in HBM (read-mostly, L2-resident): {u, v, X, Y, Z, maxErr} f32
   __shared__ double s_work[PNP_CHUNK * (156 + 60)];   // per-hypothesis EPnP matrices, lane-interleaved
   __shared__ double s_Rt[PNP_CHUNK][12];
@@ -1023,7 +1026,10 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
   __shared__ int s_cnt[PNP_CHUNK];
   __shared__ double s_RtRef[12];
   __shared__ double s_mtm[144], s_terms[64 * 9], s_red[64];
-  const int f = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x;
+  // persistent waves: the grid may be smaller than the batch (launch_pnp)
+  for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
+  __syncthreads();
   const int cap = tb.kp_cap;
   const sd_keypoint* kps = kps_all + (size_t)f * cap;
   const int nkp = min(nkp_all[f], cap);   // mvpMapPointMatches.size()
@@ -1089,7 +1095,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
   }
   if (N < minInl) {
     if (lane == 0) info[2] = 1;   // bNoMore
-    return;
+    continue;
   }
   const int total = max(maxIts, pp.n_iterations);   // while (mnIterations < maxIts || nCurrent < nIterations)
   const int nwords = (N + 63) >> 6;
@@ -1229,7 +1235,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
       T_out[15] = 1.f;
       info[0] = 1; info[1] = acc_cnt; info[2] = 0; info[3] = acc_iters; info[7] = 1;
     }
-    return;
+    continue;
   }
   // ---- iterations exhausted
   if (lane == 0) {
@@ -1250,6 +1256,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
       info[1] = best;
     }
   }
+  }   // frames of this wave
 }
 
 // diagnostics: EPnP alone on explicit correspondences (one lane)
@@ -1322,7 +1329,10 @@ int read_pnp_prof(unsigned long long* out32, int reset) {
 
 int launch_pnp(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sigma2, const PnpParams& pp,
                int n_frames, hipStream_t s) {
-  hipLaunchKernelGGL(k_pnp, dim3(n_frames), dim3(64), 0, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam, d_sigma2, pp);
+  static const int grid_cap = [] { const char* e = getenv("SD_PNP_GRID"); return e ? atoi(e) : 0; }();
+  const int grid = grid_cap > 0 ? std::min(n_frames, grid_cap) : n_frames;
+  hipLaunchKernelGGL(k_pnp, dim3(grid), dim3(64), 0, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam, d_sigma2, pp,
+                     n_frames);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }
