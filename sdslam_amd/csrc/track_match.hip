@@ -10,11 +10,13 @@
 // One workgroup per frame.  The 64x48 bucket grid is built by sorting (cell, index) keys in LDS
 // with cell = ix*48 + iy, so the reference's candidate order (ix outer, iy inner, ascending
 // index inside a cell) is, for every grid column ix, one contiguous run of the sorted array.
-// The assignment loop is sequential by definition (a keypoint claimed by an earlier map point
-// with Observations() > 0 is skipped by later ones; otherwise later points overwrite), so one
-// wavefront walks the last frame's points in order and parallelises each point's window:
-// lanes take candidates, compute Hamming distances, and a wave-min over (dist, order, index)
-// yields the reference's "first strict minimum".  Stereo / RGB-D gates (mvuRight, bForward /
+// Two phases.  (1) Everything that does not depend on earlier assignments -- projection, window,
+// level / distance / uRight gates, Hamming distances -- runs for all points in parallel (one wave
+// per point, lanes take candidates) and leaves each point's candidate keys
+// (dist, order-in-vIndices2, index) in an LDS list.  (2) The assignment loop is sequential by
+// definition (a keypoint claimed by an earlier map point with Observations() > 0 is skipped by
+// later ones; otherwise later points overwrite): one wavefront walks the points in order, drops
+// claimed candidates and takes the wave-min key = the reference's "first strict minimum".  Stereo / RGB-D gates (mvuRight, bForward /
 // bBackward octave windows) follow src/ORBmatcher.cc:965-966,999-1004,1020-1025; keypoints are
 // the undistorted ones (Frame::mvKeysUn).
 #include <hip/hip_runtime.h>
@@ -24,44 +26,189 @@
 
 namespace sd {
 
-#define MT_MAXKP 2048
+#define MT_MAXKP 2048      // keypoints per frame supported by the 11-bit index fields
+#define MT_WAVES 4
+#define MT_LIST_CAP 4096   // candidate keys per frame kept in LDS (more: per-point slow path)
 #define GRID_COLS 64
 #define GRID_ROWS 48
 #define TH_HIGH 100
 #define HISTO_LENGTH 30
 
-__global__ __launch_bounds__(256) void k_match(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
-                                               const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
-                                               const float* __restrict__ sf, float th, int mono, int check_ori) {
-  __shared__ uint32_t s_key[MT_MAXKP];
-  __shared__ uint16_t s_cstart[GRID_COLS * GRID_ROWS + 2];
-  __shared__ int s_match[MT_MAXKP];
-  __shared__ uint32_t s_ev[MT_MAXKP];
-  __shared__ int s_hist[HISTO_LENGTH];
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+struct MatchGeom {   // what every per-point evaluation needs (uniform over the workgroup)
+  double R[3][3], t[3];
+  float th, invW, invH;
+  bool bForward, bBackward;
+};
+
+// Candidate keys of last-frame point i: projection, window (GetFeaturesInArea), level / distance / uRight
+// gates, Hamming distance.  Everything here is independent of earlier assignments.  All 64 lanes call.
+//   mode 0: returns the number of candidates (wave-uniform)
+//   mode 1: writes key = dist << 22 | order-in-vIndices2 << 11 | keypoint index to list[0 .. count)
+//   mode 2: returns this lane's minimum key over the candidates not claimed by a point with observations
+// *seq_total = entries of the searched cells (keys carry 11 bits of order).
+template <int MODE>
+__device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                const double* __restrict__ Xw, const uint8_t* __restrict__ mp_desc,
+                                                const int32_t* __restrict__ l_oct, const float* __restrict__ uright,
+                                                const uint32_t* s_key, const uint16_t* s_cstart, const int16_t* s_match,
+                                                const uint32_t* s_obs, const MatchGeom& G, const TrackCam& cam,
+                                                const float* __restrict__ sf, uint32_t* list, int lane, unsigned long long lt,
+                                                int* seq_total) {
+  const double xw = Xw[(size_t)i * 3], yw = Xw[(size_t)i * 3 + 1], zw = Xw[(size_t)i * 3 + 2];
+  const double X = (G.R[0][0] * xw + G.R[0][1] * yw + G.R[0][2] * zw) + G.t[0];
+  const double Y = (G.R[1][0] * xw + G.R[1][1] * yw + G.R[1][2] * zw) + G.t[1];
+  const double Z = (G.R[2][0] * xw + G.R[2][1] * yw + G.R[2][2] * zw) + G.t[2];
+  const float xc = (float)X, yc = (float)Y;
+  const float invzc = (float)(1.0 / Z);
+  uint32_t best = 0x7FFFFFFFu;
+  *seq_total = 0;
+  if (invzc < 0) return MODE == 2 ? best : 0;
+  const float u = cam.ffx * xc * invzc + cam.fcx;
+  const float v = cam.ffy * yc * invzc + cam.fcy;
+  if (u < cam.min_x || u > cam.max_x) return MODE == 2 ? best : 0;
+  if (v < cam.min_y || v > cam.max_y) return MODE == 2 ? best : 0;
+  const int nLastOctave = l_oct[i];
+  const float radius = G.th * sf[nLastOctave];
+  const int minLevel = G.bForward ? nLastOctave : (G.bBackward ? 0 : nLastOctave - 1);
+  const int maxLevel = G.bForward ? -1 : (G.bBackward ? nLastOctave : nLastOctave + 1);
+  // GetFeaturesInArea(u, v, radius, minLevel, maxLevel)
+  const int nMinCellX = max(0, (int)floorf((u - cam.min_x - radius) * G.invW));
+  if (nMinCellX >= GRID_COLS) return MODE == 2 ? best : 0;
+  const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((u - cam.min_x + radius) * G.invW));
+  if (nMaxCellX < 0) return MODE == 2 ? best : 0;
+  const int nMinCellY = max(0, (int)floorf((v - cam.min_y - radius) * G.invH));
+  if (nMinCellY >= GRID_ROWS) return MODE == 2 ? best : 0;
+  const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((v - cam.min_y + radius) * G.invH));
+  if (nMaxCellY < 0) return MODE == 2 ? best : 0;
+  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+  if (MODE != 0) {
+    const unsigned long long* dm = (const unsigned long long*)(mp_desc + (size_t)i * 32);
+    d0 = dm[0]; d1 = dm[1]; d2 = dm[2]; d3 = dm[3];
+  }
+  int seq0 = 0, w = 0;
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+    const int a = s_cstart[ix * GRID_ROWS + nMinCellY], b = s_cstart[ix * GRID_ROWS + nMaxCellY + 1];
+    for (int e0 = a; e0 < b; e0 += 64) {
+      const int e = e0 + lane;
+      bool okc = false;
+      int idx = 0;
+      if (e < b) {
+        idx = s_key[e] & 2047;
+        const sd_keypoint kp = kps[idx];
+        okc = true;
+        if (bCheckLevels) {
+          if (kp.octave < minLevel) okc = false;
+          if (maxLevel >= 0 && kp.octave > maxLevel) okc = false;
+        }
+        const float distx = kp.x - u, disty = kp.y - v;
+        if (!(fabsf(distx) < radius && fabsf(disty) < radius)) okc = false;
+        if (okc) {
+          const float ur2 = uright[idx];
+          if (ur2 > 0) {   // stereo consistency gate (src/ORBmatcher.cc:1020-1025)
+            const float ur = u - cam.bf * invzc;
+            const float er = fabsf(ur - ur2);
+            if (er > radius) okc = false;
+          }
+        }
+        if (MODE == 2 && okc) {
+          const int m = s_match[idx];
+          if (m >= 0 && ((s_obs[m >> 5] >> (m & 31)) & 1u)) okc = false;   // already holds a point with Observations() > 0
+        }
+      }
+      if (MODE == 0) {
+        w += __popcll(__ballot(okc));
+      } else if (okc) {
+        const unsigned long long* dk = (const unsigned long long*)(desc + (size_t)idx * 32);
+        const int dist = __popcll(dk[0] ^ d0) + __popcll(dk[1] ^ d1) + __popcll(dk[2] ^ d2) + __popcll(dk[3] ^ d3);
+        // NB: candidates failing the window test do not advance the reference's vIndices2 order
+        // relative to each other, so the sorted-array position is a valid order key
+        const uint32_t key = ((uint32_t)dist << 22) | ((uint32_t)(seq0 + (e - a)) << 11) | (uint32_t)idx;
+        if (MODE == 2) best = min(best, key);
+      }
+      if (MODE == 1) {
+        const unsigned long long bal = __ballot(okc);
+        if (okc) {
+          const unsigned long long* dk = (const unsigned long long*)(desc + (size_t)idx * 32);
+          const int dist = __popcll(dk[0] ^ d0) + __popcll(dk[1] ^ d1) + __popcll(dk[2] ^ d2) + __popcll(dk[3] ^ d3);
+          list[w + __popcll(bal & lt)] = ((uint32_t)dist << 22) | ((uint32_t)(seq0 + (e - a)) << 11) | (uint32_t)idx;
+        }
+        w += __popcll(bal);
+      }
+    }
+    seq0 += b - a;
+  }
+  *seq_total = seq0;
+  return MODE == 2 ? best : (uint32_t)w;
+}
+
+// Dynamic LDS layout (KP2 = power of two >= keypoint capacity, MP = max_points):
+//   u32 s_key[KP2] | u32 s_list[MT_LIST_CAP] | u32 s_pt[MP] | f32 s_kang[KP2] | u32 s_obs[(MP+31)/32] |
+//   i16 s_match[KP2] | u16 s_ev[KP2] | u16 s_cstart[64*48+2] | int s_hist[30] | int s_nlist
+__global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
+                                                          const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
+                                                          const float* __restrict__ sf, float th, int mono, int check_ori, int KP2) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int MP = tb.max_points;
+  uint32_t* s_key = (uint32_t*)smem;
+  uint32_t* s_list = s_key + KP2;
+  uint32_t* s_pt = s_list + MT_LIST_CAP;
+  float* s_kang = (float*)(s_pt + MP);
+  uint32_t* s_obs = (uint32_t*)(s_kang + KP2);
+  int16_t* s_match = (int16_t*)(s_obs + ((MP + 31) >> 5));
+  uint16_t* s_ev = (uint16_t*)(s_match + KP2);
+  uint16_t* s_cstart = s_ev + KP2;
+  int* s_hist = (int*)(((uintptr_t)(s_cstart + GRID_COLS * GRID_ROWS + 2) + 3) & ~(uintptr_t)3);
+  int* s_nlist = s_hist + HISTO_LENGTH;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = 64 * MT_WAVES;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int cap = tb.kp_cap;
   const sd_keypoint* kps = kps_all + (size_t)f * cap;
   const uint8_t* desc = desc_all + (size_t)f * cap * 32;
-  const int N = min(nkp_all[f], min(cap, MT_MAXKP));
-  const float invW = (float)GRID_COLS / (float)(cam.max_x - cam.min_x);   // mfGridElementWidthInv
-  const float invH = (float)GRID_ROWS / (float)(cam.max_y - cam.min_y);
+  const int N = min(nkp_all[f], min(cap, KP2));
+  MatchGeom G;
+  G.th = th;
+  G.invW = (float)GRID_COLS / (float)(cam.max_x - cam.min_x);   // mfGridElementWidthInv
+  G.invH = (float)GRID_ROWS / (float)(cam.max_y - cam.min_y);
+  const int M = MP;
+  const uint8_t* valid = tb.valid + (size_t)f * M;
+  const double* Xw = tb.Xw + (size_t)f * M * 3;
+  const uint8_t* mp_desc = tb.mp_desc + (size_t)f * M * 32;
+  const int32_t* l_oct = tb.octave + (size_t)f * M;
+  const float* l_ang = tb.angle + (size_t)f * M;
+  const int32_t* l_obs = tb.obs + (size_t)f * M;
+  const int n_last = min(tb.n_last[f], M);
+  const float* uright = tb.uright + (size_t)f * cap;
 
   // ---- AssignFeaturesToGrid: key = cell << 11 | index (PosInGrid uses round())
-  for (int i = tid; i < MT_MAXKP; i += 256) {
+  for (int i = tid; i < KP2; i += NT) {
     uint32_t key = 0xFFFFFFFFu;
+    float ang = 0.f;
     if (i < N) {
-      const float x = kps[i].x, y = kps[i].y;
-      const int posX = (int)roundf((x - cam.min_x) * invW);
-      const int posY = (int)roundf((y - cam.min_y) * invH);
+      const sd_keypoint kp = kps[i];
+      ang = kp.angle;
+      const int posX = (int)roundf((kp.x - cam.min_x) * G.invW);
+      const int posY = (int)roundf((kp.y - cam.min_y) * G.invH);
       if (!(posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS)) key = ((uint32_t)(posX * GRID_ROWS + posY) << 11) | (uint32_t)i;
     }
     s_key[i] = key;
+    s_kang[i] = ang;
     s_match[i] = -1;   // CurrentFrame.mvpMapPoints filled with NULL (src/Tracking.cc:676)
   }
+  for (int w = tid; w < ((MP + 31) >> 5); w += NT) {   // Observations() > 0 flags of the last frame's points
+    uint32_t bits = 0;
+    for (int k = 0; k < 32; k++) {
+      const int m = w * 32 + k;
+      if (m < n_last && l_obs[m] > 0) bits |= 1u << k;
+    }
+    s_obs[w] = bits;
+  }
+  if (tid < HISTO_LENGTH) s_hist[tid] = 0;
+  if (tid == 0) *s_nlist = 0;
   __syncthreads();
-  for (int k = 2; k <= MT_MAXKP; k <<= 1)
+  for (int k = 2; k <= KP2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < MT_MAXKP; i += 256) {
+      for (int i = tid; i < KP2; i += NT) {
         int ixj = i ^ j;
         if (ixj > i) {
           uint32_t a = s_key[i], b = s_key[ixj];
@@ -74,9 +221,9 @@ __global__ __launch_bounds__(256) void k_match(const sd_keypoint* __restrict__ k
       }
       __syncthreads();
     }
-  for (int c = tid; c <= GRID_COLS * GRID_ROWS; c += 256) {
+  for (int c = tid; c <= GRID_COLS * GRID_ROWS; c += NT) {
     const uint32_t target = (uint32_t)c << 11;
-    int lo = 0, hi = MT_MAXKP;
+    int lo = 0, hi = KP2;
     while (lo < hi) {
       int mid = (lo + hi) >> 1;
       if (s_key[mid] < target) lo = mid + 1;
@@ -84,104 +231,71 @@ __global__ __launch_bounds__(256) void k_match(const sd_keypoint* __restrict__ k
     }
     s_cstart[c] = (uint16_t)lo;
   }
-  if (tid < HISTO_LENGTH) s_hist[tid] = 0;
+  {
+    const double* Tc = tb.Tcur + (size_t)f * 16;   // column-major
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) G.R[r][c] = Tc[c * 4 + r];
+      G.t[r] = Tc[12 + r];
+    }
+    // bForward / bBackward: tlc = Rlw * (-Rcw^T tcw) + tlw compared with the baseline mb
+    G.bForward = G.bBackward = false;
+    if (!mono) {
+      const double* Tl = tb.Tref + (size_t)f * 16;
+      double twc[3], tlc2;
+      for (int i = 0; i < 3; i++) twc[i] = (-G.R[0][i]) * G.t[0] + (-G.R[1][i]) * G.t[1] + (-G.R[2][i]) * G.t[2];
+      tlc2 = (Tl[0 * 4 + 2] * twc[0] + Tl[1 * 4 + 2] * twc[1] + Tl[2 * 4 + 2] * twc[2]) + Tl[12 + 2];
+      G.bForward = tlc2 > cam.mb;
+      G.bBackward = -tlc2 > cam.mb;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1 (all waves, one wave per last-frame point): candidate keys into the LDS list.
+  // s_pt[i] = 0 (nothing to do) | offset << 16 | count | 0xFFFFFFFF (list full: evaluate in phase 2)
+  for (int i0 = 0; i0 < n_last; i0 += MT_WAVES) {
+    const int i = i0 + wave;
+    if (i >= n_last) break;
+    uint32_t pc = 0;
+    if (valid[i]) {
+      int seq = 0;
+      const int cnt = (int)match_point<0>(i, kps, desc, Xw, mp_desc, l_oct, uright, s_key, s_cstart, s_match, s_obs, G, cam, sf, nullptr, lane,
+                                          lt, &seq);
+      if (cnt > 0) {
+        int off = 0;
+        if (lane == 0) off = atomicAdd(s_nlist, cnt);
+        off = __shfl(off, 0);
+        if (off + cnt > MT_LIST_CAP || seq >= 2048 || cnt > 0xffff) {
+          pc = 0xFFFFFFFFu;
+        } else {
+          match_point<1>(i, kps, desc, Xw, mp_desc, l_oct, uright, s_key, s_cstart, s_match, s_obs, G, cam, sf, s_list + off, lane, lt, &seq);
+          pc = ((uint32_t)off << 16) | (uint32_t)cnt;
+        }
+      }
+    }
+    if (lane == 0) s_pt[i] = pc;
+  }
   __syncthreads();
   if (tid >= 64) return;   // one wavefront runs the order-dependent assignment loop
 
-  const int M = tb.max_points;
-  const uint8_t* valid = tb.valid + (size_t)f * M;
-  const double* Xw = tb.Xw + (size_t)f * M * 3;
-  const uint8_t* mp_desc = tb.mp_desc + (size_t)f * M * 32;
-  const int32_t* l_oct = tb.octave + (size_t)f * M;
-  const float* l_ang = tb.angle + (size_t)f * M;
-  const int32_t* l_obs = tb.obs + (size_t)f * M;
-  const int n_last = min(tb.n_last[f], M);
-  const double* Tc = tb.Tcur + (size_t)f * 16;   // column-major
-  double R[3][3], t[3];
-  for (int r = 0; r < 3; r++) {
-    for (int c = 0; c < 3; c++) R[r][c] = Tc[c * 4 + r];
-    t[r] = Tc[12 + r];
-  }
+  // ---- phase 2 (points in order): minimum over the candidates not claimed by a point with observations
+  // (first strict minimum = smallest key), assignment (later points overwrite), rotation histogram
   int nmatches = 0, nev = 0;
   const float factor = 1.0f / HISTO_LENGTH;
-  const float* uright = tb.uright + (size_t)f * cap;
-  // bForward / bBackward: tlc = Rlw * (-Rcw^T tcw) + tlw compared with the baseline mb
-  bool bForward = false, bBackward = false;
-  if (!mono) {
-    const double* Tl = tb.Tref + (size_t)f * 16;
-    double twc[3], tlc2;
-    for (int i = 0; i < 3; i++) twc[i] = (-R[0][i]) * t[0] + (-R[1][i]) * t[1] + (-R[2][i]) * t[2];
-    tlc2 = (Tl[0 * 4 + 2] * twc[0] + Tl[1 * 4 + 2] * twc[1] + Tl[2 * 4 + 2] * twc[2]) + Tl[12 + 2];
-    bForward = tlc2 > cam.mb;
-    bBackward = -tlc2 > cam.mb;
-  }
-
   for (int i = 0; i < n_last; i++) {
-    if (!valid[i]) continue;
-    const double xw = Xw[(size_t)i * 3], yw = Xw[(size_t)i * 3 + 1], zw = Xw[(size_t)i * 3 + 2];
-    const double X = (R[0][0] * xw + R[0][1] * yw + R[0][2] * zw) + t[0];
-    const double Y = (R[1][0] * xw + R[1][1] * yw + R[1][2] * zw) + t[1];
-    const double Z = (R[2][0] * xw + R[2][1] * yw + R[2][2] * zw) + t[2];
-    const float xc = (float)X, yc = (float)Y;
-    const float invzc = (float)(1.0 / Z);
-    if (invzc < 0) continue;
-    const float u = cam.ffx * xc * invzc + cam.fcx;
-    const float v = cam.ffy * yc * invzc + cam.fcy;
-    if (u < cam.min_x || u > cam.max_x) continue;
-    if (v < cam.min_y || v > cam.max_y) continue;
-    const int nLastOctave = l_oct[i];
-    const float radius = th * sf[nLastOctave];
-    const int minLevel = bForward ? nLastOctave : (bBackward ? 0 : nLastOctave - 1);
-    const int maxLevel = bForward ? -1 : (bBackward ? nLastOctave : nLastOctave + 1);
-    // GetFeaturesInArea(u, v, radius, minLevel, maxLevel)
-    const int nMinCellX = max(0, (int)floorf((u - cam.min_x - radius) * invW));
-    if (nMinCellX >= GRID_COLS) continue;
-    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((u - cam.min_x + radius) * invW));
-    if (nMaxCellX < 0) continue;
-    const int nMinCellY = max(0, (int)floorf((v - cam.min_y - radius) * invH));
-    if (nMinCellY >= GRID_ROWS) continue;
-    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((v - cam.min_y + radius) * invH));
-    if (nMaxCellY < 0) continue;
-    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-    const unsigned long long* dm = (const unsigned long long*)(mp_desc + (size_t)i * 32);
-    const unsigned long long d0 = dm[0], d1 = dm[1], d2 = dm[2], d3 = dm[3];
+    const uint32_t pc = s_pt[i];
+    if (pc == 0) continue;
     uint32_t best = 0x7FFFFFFFu;
-    int seq0 = 0;
-    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-      const int a = s_cstart[ix * GRID_ROWS + nMinCellY], b = s_cstart[ix * GRID_ROWS + nMaxCellY + 1];
-      for (int e0 = a; e0 < b; e0 += 64) {
-        const int e = e0 + lane;
-        if (e < b) {
-          const int idx = s_key[e] & 2047;
-          const sd_keypoint kp = kps[idx];
-          bool okc = true;
-          if (bCheckLevels) {
-            if (kp.octave < minLevel) okc = false;
-            if (maxLevel >= 0 && kp.octave > maxLevel) okc = false;
-          }
-          const float distx = kp.x - u, disty = kp.y - v;
-          if (!(fabsf(distx) < radius && fabsf(disty) < radius)) okc = false;
-          if (okc) {
-            const int m = s_match[idx];
-            bool claimed = (m >= 0) && (l_obs[m] > 0);
-            const float ur2 = uright[idx];
-            if (!claimed && ur2 > 0) {   // stereo consistency gate (src/ORBmatcher.cc:1020-1025)
-              const float ur = u - cam.bf * invzc;
-              const float er = fabsf(ur - ur2);
-              if (er > radius) claimed = true;
-            }
-            if (!claimed) {
-              const unsigned long long* dk = (const unsigned long long*)(desc + (size_t)idx * 32);
-              const int dist = __popcll(dk[0] ^ d0) + __popcll(dk[1] ^ d1) + __popcll(dk[2] ^ d2) + __popcll(dk[3] ^ d3);
-              // NB: candidates failing the window test do not advance the reference's vIndices2
-              // order relative to each other, so the sorted-array position is a valid order key
-              const uint32_t key = ((uint32_t)dist << 22) | ((uint32_t)(seq0 + (e - a)) << 11) | (uint32_t)idx;
-              best = min(best, key);
-            }
-          }
-        }
+    if (pc != 0xFFFFFFFFu) {
+      const int off = pc >> 16, cnt = pc & 0xffff;
+      for (int j = lane; j < cnt; j += 64) {
+        const uint32_t key = s_list[off + j];
+        const int m = s_match[key & 2047];
+        const bool claimed = (m >= 0) && ((s_obs[m >> 5] >> (m & 31)) & 1u);
+        if (!claimed) best = min(best, key);
       }
-      seq0 += b - a;
+    } else {
+      int seq = 0;
+      best = match_point<2>(i, kps, desc, Xw, mp_desc, l_oct, uright, s_key, s_cstart, s_match, s_obs, G, cam, sf, nullptr, lane, lt, &seq);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
@@ -189,15 +303,15 @@ __global__ __launch_bounds__(256) void k_match(const sd_keypoint* __restrict__ k
     const int bestDist = best >> 22;
     const int bestIdx2 = best & 2047;
     if (bestDist <= TH_HIGH) {
-      if (lane == 0) s_match[bestIdx2] = i;
+      if (lane == 0) s_match[bestIdx2] = (int16_t)i;
       nmatches++;
       if (check_ori) {
-        float rot = l_ang[i] - kps[bestIdx2].angle;
+        float rot = l_ang[i] - s_kang[bestIdx2];
         if (rot < 0.0) rot += 360.0f;
         int bin = (int)roundf(rot * factor);
         if (bin == HISTO_LENGTH) bin = 0;
         if (lane == 0) {
-          s_ev[nev] = ((uint32_t)bin << 16) | (uint32_t)bestIdx2;
+          s_ev[nev] = (uint16_t)((bin << 11) | bestIdx2);
           s_hist[bin]++;
         }
         nev++;
@@ -209,15 +323,15 @@ __global__ __launch_bounds__(256) void k_match(const sd_keypoint* __restrict__ k
     int ind1 = -1, ind2 = -1, ind3 = -1;
     int max1 = 0, max2 = 0, max3 = 0;
     for (int b = 0; b < HISTO_LENGTH; b++) {
-      const int s = s_hist[b];
-      if (s > max1) {
-        max3 = max2; max2 = max1; max1 = s;
+      const int sh = s_hist[b];
+      if (sh > max1) {
+        max3 = max2; max2 = max1; max1 = sh;
         ind3 = ind2; ind2 = ind1; ind1 = b;
-      } else if (s > max2) {
-        max3 = max2; max2 = s;
+      } else if (sh > max2) {
+        max3 = max2; max2 = sh;
         ind3 = ind2; ind2 = b;
-      } else if (s > max3) {
-        max3 = s;
+      } else if (sh > max3) {
+        max3 = sh;
         ind3 = b;
       }
     }
@@ -228,16 +342,16 @@ __global__ __launch_bounds__(256) void k_match(const sd_keypoint* __restrict__ k
       ind3 = -1;
     }
     for (int e = 0; e < nev; e++) {   // uniform loop; lane 0 applies
-      const uint32_t ev = s_ev[e];
-      const int bin = ev >> 16;
+      const unsigned ev = s_ev[e];
+      const int bin = ev >> 11;
       if (bin != ind1 && bin != ind2 && bin != ind3) {
-        if (lane == 0) s_match[ev & 0xffff] = -1;
+        if (lane == 0) s_match[ev & 2047] = -1;
         nmatches--;
       }
     }
   }
   int32_t* out = tb.cur_match + (size_t)f * cap;
-  for (int i = lane; i < cap; i += 64) out[i] = i < MT_MAXKP ? s_match[i] : -1;
+  for (int i = lane; i < cap; i += 64) out[i] = i < KP2 ? (int32_t)s_match[i] : -1;
   if (lane == 0) tb.n_matches[f] = nmatches;
 }
 
@@ -274,8 +388,14 @@ int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const Tr
 
 int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, int n_frames, float th,
                  int mono, int check_ori, hipStream_t s) {
-  hipLaunchKernelGGL(k_match, dim3(n_frames), dim3(256), 0, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_desc, cur->d_nout, tb, cam, d_sf, th, mono,
-                     check_ori);
+  int KP2 = 64;
+  while (KP2 < tb.kp_cap) KP2 <<= 1;
+  SD_REQUIRE(KP2 <= MT_MAXKP && tb.max_points <= 2048, SD_ERR_CAPACITY, "matcher supports at most 2048 keypoints / map points per frame");
+  const int MP = tb.max_points;
+  const size_t lds = (size_t)KP2 * 4 + MT_LIST_CAP * 4 + (size_t)MP * 4 + (size_t)KP2 * 4 + (size_t)((MP + 31) >> 5) * 4 + (size_t)KP2 * 2 +
+                     (size_t)KP2 * 2 + (GRID_COLS * GRID_ROWS + 2) * 2 + 4 + (HISTO_LENGTH + 1) * 4;
+  hipLaunchKernelGGL(k_match, dim3(n_frames), dim3(64 * MT_WAVES), lds, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_desc,
+                     cur->d_nout, tb, cam, d_sf, th, mono, check_ori, KP2);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }
