@@ -481,14 +481,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
                                                     const CellGeom* __restrict__ cells,
                                                     const uint8_t* __restrict__ pyr,
                                                     uint32_t* __restrict__ cand,
-                                                    int32_t* __restrict__ cell_count) {
+                                                    int32_t* __restrict__ cell_count, int cell0) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int wcnt[4];
-  const CellGeom C = cells[blockIdx.x];
+  const int cell = blockIdx.x + cell0;   // launched per level: the cells of a level are contiguous
+  const CellGeom C = cells[cell];
   const int frame = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (C.zw <= 0 || C.zh <= 0) {
-    if (tid == 0) cell_count[(size_t)frame * P->ncells + blockIdx.x] = 0;
+    if (tid == 0) cell_count[(size_t)frame * P->ncells + cell] = 0;
     return;
   }
   const LevelGeom L = P->lv[C.level];
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ 
     __syncthreads();
     FPROF(6);
   }
-  if (tid == 0) cell_count[(size_t)frame * P->ncells + blockIdx.x] = min(total, (int)C.cap);
+  if (tid == 0) cell_count[(size_t)frame * P->ncells + cell] = min(total, (int)C.cap);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1138,6 +1139,10 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
     h->set_busy[h->set] = false;
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[0], s));
+  bool fast_started = false;
+  // the previous call's select (main stream) read d_cand / d_cell_count: FAST must not overwrite them early
+  SD_HIP_CHECK(hipEventRecord(h->ev_fast_done, s));
+  SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_fast_done, 0));
   const bool src_aligned = (((uintptr_t)d_imgs | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) == 0;
   for (int l = 0; l < P.nlevels; l++) {
     const LevelGeom& L = P.lv[l];
@@ -1146,8 +1151,7 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
     if (!split) {   // generic single-pass kernel (exact-2x INTER_AREA levels, odd source alignment, tiny levels)
       dim3 grid((L.pstride + 255) / 256, (L.prows + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), n), block(64, 4, 1);
       hipLaunchKernelGGL(k_pyr_level, grid, block, 0, s, L, S, (size_t)P.pyr_frame_bytes, l, d_imgs, stride, frame_stride, h->d_pyr);
-      continue;
-    }
+    } else {
     auto magic = [](unsigned d) { return (unsigned)(0xFFFFFFFFull / d) + 1u; };   // e / d == umulhi(e, magic) for e < 2^31 / d
     const int G = (L.w - 1) / 4;
     const int T = 5 + (((L.w + 2 * SD_EDGE + 3) & ~3) - 20 - 4 * G) / 4;
@@ -1158,6 +1162,16 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
                        l, d_imgs, stride, frame_stride, h->d_pyr, G, T, magic((unsigned)T));
     hipLaunchKernelGGL(k_pyr_rows, dim3((unsigned)((2 * SD_EDGE * wpr + 255) / 256), n), dim3(256), 0, s, L, (size_t)P.pyr_frame_bytes,
                        h->d_pyr, wpr, magic((unsigned)wpr));
+    }
+    // FAST of this level starts now, on its own stream
+    if (L.ncells > 0) {
+      SD_HIP_CHECK(hipEventRecord(h->ev_level[l], s));
+      SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_level[l], 0));
+      if (prof && !fast_started) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
+      fast_started = true;
+      hipLaunchKernelGGL(k_fast_cells, dim3(L.ncells, n), dim3(256), hp.fast_lds_bytes, h->fast_stream, h->d_plan, h->d_cells,
+                         h->d_pyr, h->d_cand, h->d_cell_count, L.cell0);
+    }
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], s));
   // blur on the auxiliary stream, beside FAST + selection
@@ -1168,11 +1182,13 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
                      h->d_blur, h->d_sel_count);
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[6], h->aux_stream));
   SD_HIP_CHECK(hipEventRecord(h->ev_blur_done, h->aux_stream));
-  if (P.ncells > 0) {
-    hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, n), dim3(256), hp.fast_lds_bytes, s, h->d_plan, h->d_cells,
-                       h->d_pyr, h->d_cand, h->d_cell_count);
+  if (prof) {
+    if (!fast_started) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
+    SD_HIP_CHECK(hipEventRecord(ev[2], h->fast_stream));
   }
-  if (prof) SD_HIP_CHECK(hipEventRecord(ev[2], s));
+  SD_HIP_CHECK(hipEventRecord(h->ev_fast_done, h->fast_stream));
+  SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_fast_done, 0));
+  if (prof) SD_HIP_CHECK(hipEventRecord(ev[9], s));
   hipLaunchKernelGGL(k_select_level, dim3(P.nlevels, n), dim3(64 * SEL_WAVES), 0, s, h->d_plan, h->d_cells, h->d_cand,
                      h->d_cell_count, h->d_scratch, h->d_sel, h->d_sel_count);
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[7], s));
@@ -1295,8 +1311,11 @@ int sd_orb_create(int nfeatures, float scale_factor, int nlevels, int th_fast, i
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_extract_done, hipEventDisableTiming);
   if (e == hipSuccess) select_set(h, 0);
   for (int r = 0; r < sd_orb::kRing && e == hipSuccess; r++)
-    for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
+    for (int i = 0; i < 10 && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->fast_stream, hipStreamNonBlocking);
+  for (int i = 0; i < SD_MAX_LEVELS && e == hipSuccess; i++) e = hipEventCreateWithFlags(&h->ev_level[i], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fast_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_pyr_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_blur_done, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -1323,9 +1342,13 @@ void sd_orb_destroy(sd_orb* h) {
     if (h->ev_set_free[i]) (void)hipEventDestroy(h->ev_set_free[i]);
   if (h->ev_extract_done) (void)hipEventDestroy(h->ev_extract_done);
   for (int r = 0; r < sd_orb::kRing; r++)
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < 10; i++)
       if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
   if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  if (h->fast_stream) { (void)hipStreamSynchronize(h->fast_stream); (void)hipStreamDestroy(h->fast_stream); }
+  for (int i = 0; i < SD_MAX_LEVELS; i++)
+    if (h->ev_level[i]) (void)hipEventDestroy(h->ev_level[i]);
+  if (h->ev_fast_done) (void)hipEventDestroy(h->ev_fast_done);
   if (h->ev_pyr_done) (void)hipEventDestroy(h->ev_pyr_done);
   if (h->ev_blur_done) (void)hipEventDestroy(h->ev_blur_done);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1577,8 +1600,9 @@ int sd_orb_stage_ms(sd_orb* h, float* ms_out, int cap) {
   SD_HIP_CHECK(hipStreamSynchronize(h->stream));
   const int n = std::min(h->ev_calls, (int)sd_orb::kRing);
   for (int i = 0; i < ST_COUNT; i++) ms_out[i] = 0.f;
-  static const int kBegin[ST_COUNT] = {0, 1, 2, 3, 4}, kEnd[ST_COUNT] = {1, 2, 7, 6, 5};
+  static const int kBegin[ST_COUNT] = {0, 8, 9, 3, 4}, kEnd[ST_COUNT] = {1, 2, 7, 6, 5};
   SD_HIP_CHECK(hipStreamSynchronize(h->aux_stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->fast_stream));
   for (int r = 0; r < n; r++) {
     const int slot = (h->ev_calls - 1 - r) % sd_orb::kRing;
     for (int i = 0; i < ST_COUNT; i++) {

@@ -19,6 +19,11 @@ struct sd_orb {
   // blur depends only on the pyramid: it runs on aux_stream beside FAST + selection
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_pyr_done = nullptr, ev_blur_done = nullptr, ev_blur_start = nullptr;
+  // FAST of level l needs only level l of the pyramid: it runs on fast_stream as soon as that level is complete,
+  // beside the (small, dependent) resize launches of the remaining levels
+  hipStream_t fast_stream = nullptr;
+  hipEvent_t ev_level[SD_MAX_LEVELS] = {};
+  hipEvent_t ev_fast_done = nullptr;
   // Output sets.  What a tracker reads (padded pyramid, keypoints, descriptors, counts) exists once
   // or -- after sd::orb_enable_double_buffer, which sd_track_create calls on its `cur` handle -- twice:
   // extraction alternates between the sets, so batch n+1 is extracted on `stream` while the tracker
@@ -59,8 +64,9 @@ struct sd_orb {
   bool profiling = false;
   // ring of per-call stage events: the bench reads mean stage times over its whole timed region
   static const int kRing = 128;
-  // per call: [0] start, [1] pyramid end, [2] FAST end, [7] select end, [3]/[6] blur start/end (aux stream), [4]/[5] descriptor start/end
-  hipEvent_t ev[kRing][8] = {};
+  // per call: [0] start, [1] pyramid end, [8]/[2] FAST start/end (fast stream), [9]/[7] select start/end, [3]/[6] blur start/end
+  // (aux stream), [4]/[5] descriptor start/end
+  hipEvent_t ev[kRing][10] = {};
   int ev_calls = 0;   // calls recorded since profiling was (re-)enabled
 };
 

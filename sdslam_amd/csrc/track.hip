@@ -9,6 +9,7 @@
 //                                                 -> sd_track_pnp
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -125,7 +126,9 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
       // they are free and leave the rest of the machine to the extraction kernels of the next batch
       int lo = 0, hi = 0;
       e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-      if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->pnp_stream, hipStreamNonBlocking, hi);
+      const char* pe = getenv("SD_TRACK_PRIO");   // experiments: "low" | "normal" | default high
+      const int prio = (pe && pe[0] == 'l') ? lo : ((pe && pe[0] == 'n') ? (lo + hi) / 2 : hi);
+      if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->pnp_stream, hipStreamNonBlocking, prio);
     }
     if (e != hipSuccess) {
       set_error(std::string("sd_track_create: ") + hipGetErrorString(e));
