@@ -255,3 +255,52 @@ def test_epnp_device_vs_oracle(sd, oracle):
         R, t, e = oracle.epnp(Xw, uv, K)
         Rg, tg, eg = debug_epnp(Xw, uv, K)
         assert np.abs(R - Rg).max() <= 1e-9 and np.abs(t - tg).max() <= 1e-9, (trial, n, np.abs(t - tg).max())
+
+
+def test_pipelined_steps_match_isolated_steps(sd, oracle):
+    """Back-to-back steps without host synchronisation (extraction of batch n+1 overlaps tracking of batch n on
+    the double-buffered extractor) give exactly the results of the same steps run one at a time."""
+    B = 4
+    scenes_a = [synth.make_scene(60 + i, (0.02, -0.01, 0.015), (0.4, -0.3, 0.5)) for i in range(B)]
+    scenes_b = [synth.make_scene(70 + i, (-0.02, 0.02, -0.01), (-0.5, 0.2, 0.3)) for i in range(B)]
+    cur = sd.ORBextractor(*CFG, 640, 480, B)
+    ref = sd.ORBextractor(*CFG, 640, 480, B)
+    trk = sd.Tracker(cur, ref, max_points=1000, max_batch=B, pnp_max_iterations=200)
+    trk.set_camera(*K, 0.0, BOUNDS)
+    rs = synth.glibc_rand_stream(800)
+    trk.set_rand(0, np.tile(rs, (B, 1)))
+    from sdslam_amd.capi import DeviceBuffer
+
+    def prepare(scenes):
+        rk, rd, rn = ref.extract_batch(np.stack([s["ref"] for s in scenes]))
+        trk.set_last(0, [synth.tracking_case(i, rk[i, :rn[i]], rd[i, :rn[i]]) for i in range(B)])
+        trk.set_poses(0, [s["T_ref"] for s in scenes], [s["T_cur"] for s in scenes])
+
+    def run(d_frames):
+        cur.extract_batch_device(d_frames.ptr, B, 640, 480)
+        trk.align(B, 0)
+        trk.match(B, 8.0, True, True)
+        trk.pnp(B, 0.99, 10, 200, 4, 0.28, 5.991, 200)
+
+    def results():
+        al, (cm, nm), pn = trk.get_align(0, B), trk.get_matches(0, B), trk.get_pnp(0, B)
+        k, d, n = cur.download(0, B)
+        return np.stack(al["T"]), cm.copy(), nm.copy(), pn["T"].copy(), pn["inliers"].copy(), k.copy(), d.copy(), n.copy()
+
+    bufs = []
+    for scenes in (scenes_a, scenes_b):
+        fr = np.stack([s["cur"] for s in scenes])
+        db = DeviceBuffer(fr.nbytes)
+        db.upload(fr)
+        bufs.append(db)
+    # isolated: B alone (same last-frame state as in the pipelined run below)
+    prepare(scenes_b)
+    run(bufs[1])
+    iso = results()
+    # pipelined: A, then B, then A, then B without any host sync in between; last results must equal `iso`
+    for j in (0, 1, 0, 1):
+        run(bufs[j])
+    pip = results()
+    for x, y in zip(iso, pip):
+        assert np.array_equal(x, y)
+    assert pip[2].min() > 50
