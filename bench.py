@@ -119,7 +119,8 @@ def pmc_for_stage(stage, batch):
         if not e or "FETCH_bytes_corrected_per_launch" not in e:
             continue
         found = True
-        calls = 8 if k.startswith("k_pyr") else 1     # one launch per pyramid level
+        # launches per step: relative to a kernel that runs once per step (the pyramid and FAST kernels run per level)
+        calls = max(1, round(e.get("duration_ns_samples", 1) / max(d.get("k_select_level", {}).get("duration_ns_samples", 1), 1)))
         tot += calls * (e["FETCH_bytes_corrected_per_launch"] + e.get("WRITE_bytes_per_launch", 0.0))
         valu += calls * e.get("SQ_INSTS_VALU_per_launch", 0.0)
         dur += calls * e.get("duration_ns_per_launch", 0.0)
