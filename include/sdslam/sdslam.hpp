@@ -148,6 +148,24 @@ class TrackBatch {
   void ComputeStereoFromRGBD(int n_frames, const float* imDepth, int cols, int rows, int step_elems, size_t frame_step_elems) {
     check(sd_track_stereo_from_depth(h_, n_frames, imDepth, cols, rows, step_elems, frame_step_elems));
   }
+  // TrackLocalMap: local map points of one frame (src/Tracking.cc:898-939), flattened in mvpLocalMapPoints order
+  struct LocalMapView {
+    std::vector<uint8_t> cand;                 // reaches isInFrustum: !isBad() && mnLastFrameSeen != frame id
+    std::vector<double> Xw, normal;            // GetWorldPos(), GetNormal()  (3 per point)
+    std::vector<float> min_dist, max_dist;     // GetMinDistanceInvariance(), GetMaxDistanceInvariance()
+    std::vector<float> mf_max_dist;            // mfMaxDistance (MapPoint::PredictScale)
+    std::vector<uint8_t> desc;                 // GetDescriptor(), 32 per point
+    std::vector<int32_t> obs;                  // Observations()
+  };
+  void SetLocalMap(int frame, const LocalMapView& v, const uint8_t* kp_claimed /* kp_cap flags or nullptr */) {
+    LocalMapView p = v;
+    const int n = (int)v.cand.size();
+    p.cand.resize(max_points_); p.Xw.resize((size_t)max_points_ * 3); p.normal.resize((size_t)max_points_ * 3);
+    p.min_dist.resize(max_points_); p.max_dist.resize(max_points_); p.mf_max_dist.resize(max_points_);
+    p.desc.resize((size_t)max_points_ * 32); p.obs.resize(max_points_);
+    check(sd_track_set_local(h_, frame, 1, &n, p.cand.data(), p.Xw.data(), p.normal.data(), p.min_dist.data(), p.max_dist.data(),
+                             p.mf_max_dist.data(), p.desc.data(), p.obs.data(), kp_claimed));
+  }
   // stereo frames: mvuRight computed by the caller (-1 = no match)
   void SetURight(int frame, const float* mvuRight, int n) { check(sd_track_set_uright(h_, frame, 1, mvuRight, n)); }
   sd_track* handle() { return h_; }
@@ -184,6 +202,16 @@ class ORBmatcher {
     check(sd_track_match(batch.handle(), n_frames, th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0));
   }
   // CurrentFrame.mvpMapPoints as indices into LastFrame (-1 = NULL); returns nmatches
+  // SearchByProjection(Frame&, const vector<MapPoint*>&, th): isInFrustum (viewing cosine limit 0.5) + the local-map search
+  void SearchLocalPoints(TrackBatch& batch, int n_frames, float th) {
+    check(sd_track_match_local(batch.handle(), n_frames, th, mfNNratio, 0.5f));
+  }
+  int LocalResult(TrackBatch& batch, int frame, std::vector<int32_t>& local_match, int kp_cap) {
+    local_match.resize(kp_cap);
+    int32_t n = 0;
+    check(sd_track_get_local(batch.handle(), frame, 1, local_match.data(), kp_cap, &n, nullptr, nullptr, nullptr, nullptr));
+    return n;
+  }
   int Result(TrackBatch& batch, int frame, std::vector<int32_t>& mvpMapPoints, int kp_cap) {
     mvpMapPoints.resize(kp_cap);
     int32_t n = 0;

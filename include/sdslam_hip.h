@@ -163,6 +163,21 @@ int sd_track_stereo_from_depth(sd_track* h, int n_frames, const float* depth, in
                                int stride_elems, size_t frame_stride_elems);
 int sd_track_get_stereo(sd_track* h, int frame0, int n_frames, float* uright, float* depth, int cap);
 
+/* TrackLocalMap's search (reference src/Tracking.cc:898-939): Frame::isInFrustum (src/Frame.cc:215-269, incl.
+ * MapPoint::PredictScale src/MapPoint.cc:371-385) for every local map point with cand != 0, then
+ * ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:43-126) with
+ * mfNNratio = nnratio, at the frames' current poses.  Per-point arrays are [n_frames][max_points]:
+ * min_dist / max_dist = GetMin/MaxDistanceInvariance(), mf_max_dist = mfMaxDistance, normal = GetNormal(),
+ * obs = Observations(); kp_claimed [n_frames][kp_cap] (may be NULL) marks keypoints that already hold a map
+ * point with Observations() > 0.  Results: local_match[kp] = index of the assigned local point or -1,
+ * in_view = mbTrackInView, proj3 = {mTrackProjX, mTrackProjY, mTrackProjXR}, level = mnTrackScaleLevel. */
+int sd_track_set_local(sd_track* h, int frame0, int n_frames, const int32_t* n_local, const uint8_t* cand, const double* Xw,
+                       const double* normal, const float* min_dist, const float* max_dist, const float* mf_max_dist,
+                       const uint8_t* desc, const int32_t* obs, const uint8_t* kp_claimed);
+int sd_track_match_local(sd_track* h, int n_frames, float th, float nnratio, float viewing_cos_limit);
+int sd_track_get_local(sd_track* h, int frame0, int n_frames, int32_t* local_match, int cap, int32_t* n_matches,
+                       uint8_t* in_view, float* proj3, int32_t* level, float* view_cos);
+
 int sd_track_align(sd_track* h, int n_frames, int mode);
 int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori);
 int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers, int max_iterations,

@@ -247,6 +247,41 @@ def search_by_projection(kps_un, desc, sf, bounds, K, T_cw, T_lw, last, th=8.0, 
     return n, cm
 
 
+def search_local_points(kps_un, desc, sf, log_sf, bounds, K, mbf, T_cw, pts, th=1.0, nnratio=0.8, u_right=None, kp_claimed=None,
+                        cos_limit=0.5):
+    """TrackLocalMap search: isInFrustum + PredictScale + SearchByProjection(F, vpMapPoints, th).  `pts` = dict(cand, Xw,
+    normal, min_dist, max_dist, mf_max_dist, desc, obs).  Returns dict(n, match[N], in_view[M], proj[M,3], level[M], cos[M])."""
+    L = lib()
+    kps_un = np.ascontiguousarray(kps_un)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    N, M = len(kps_un), len(pts["cand"])
+    sf = np.ascontiguousarray(sf, np.float32)
+    Tc = _cm(T_cw)
+    cand = np.ascontiguousarray(pts["cand"], np.uint8)
+    Xw = np.ascontiguousarray(pts["Xw"], np.float64)
+    nr = np.ascontiguousarray(pts["normal"], np.float64)
+    mn = np.ascontiguousarray(pts["min_dist"], np.float32)
+    mx = np.ascontiguousarray(pts["max_dist"], np.float32)
+    mf = np.ascontiguousarray(pts["mf_max_dist"], np.float32)
+    md = np.ascontiguousarray(pts["desc"], np.uint8)
+    ob = np.ascontiguousarray(pts["obs"], np.int32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    kc = None if kp_claimed is None else np.ascontiguousarray(kp_claimed, np.uint8)
+    match = np.zeros(N, np.int32)
+    inv = np.zeros(M, np.uint8)
+    proj = np.zeros((M, 3), np.float32)
+    lvl = np.zeros(M, np.int32)
+    cs = np.zeros(M, np.float32)
+    L.orc_search_local_points.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 10 + \
+        [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_float] * 3 + [C.c_void_p] * 5
+    n = L.orc_search_local_points(N, _p(kps_un), _p(desc), _p(ur) if ur is not None else None, _p(sf), len(sf), float(log_sf),
+                                  float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]),
+                                  float(K[0]), float(K[1]), float(K[2]), float(K[3]), float(mbf), _p(Tc), M, _p(cand), _p(Xw), _p(nr),
+                                  _p(mn), _p(mx), _p(mf), _p(md), _p(ob), _p(kc) if kc is not None else None, float(th), float(nnratio),
+                                  float(cos_limit), _p(match), _p(inv), _p(proj), _p(lvl), _p(cs))
+    return dict(n=n, match=match, in_view=inv.astype(bool), proj=proj, level=lvl, cos=cs)
+
+
 def stereo_from_rgbd(kps, kps_un, depth, mbf):
     """Frame::ComputeStereoFromRGBD -> (mvuRight, mvDepth)."""
     L = lib()

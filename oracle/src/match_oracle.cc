@@ -248,6 +248,123 @@ void orc_undistort_points(int n, const float* xy_in, float fxf, float fyf, float
   }
 }
 
+// TrackLocalMap's search: Frame::isInFrustum (src/Frame.cc:215-269) + MapPoint::PredictScale
+// (src/MapPoint.cc:371-385) for every candidate local map point, then
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:43-126) with
+// mfNNratio = nnratio.  MapPoints are flattened to arrays of length M in vpMapPoints order:
+//   cand[i] != 0      the point reaches isInFrustum (not bad, mnLastFrameSeen != frame id; src/Tracking.cc:916-923)
+//   Xw, normal        GetWorldPos(), GetNormal()                       (3 doubles each)
+//   min_dist/max_dist GetMinDistanceInvariance() / GetMaxDistanceInvariance()  (0.8 mfMin, 1.2 mfMax: floats)
+//   mf_max_dist       mfMaxDistance (PredictScale)
+//   mp_desc, mp_obs   GetDescriptor(), Observations()
+// kp_claimed[idx] != 0: F.mvpMapPoints[idx] already holds a point with Observations() > 0.
+// Unqualified log() on a float resolves to the float overload through libstdc++'s <math.h> (std::log(float)),
+// which is how the restatement reads `ceil(log(ratio)/mfLogScaleFactor)` and `mfLogScaleFactor = log(mfScaleFactor)`.
+// Outputs: local_match[N] = index of the local point assigned to keypoint idx or -1; in_view[M], proj[M][3] =
+// (mTrackProjX, mTrackProjY, mTrackProjXR), level[M], view_cos[M] (only meaningful where in_view).  Returns nmatches.
+int orc_search_local_points(int N, const void* keysUn_, const uint8_t* desc, const float* uRight, const float* scaleFactors, int nLevels,
+                            float logScaleFactor, float minX, float maxX, float minY, float maxY, float fx, float fy, float cx, float cy,
+                            float mbf, const double* Tcw_cm, int M, const uint8_t* cand, const double* Xw, const double* normal,
+                            const float* min_dist, const float* max_dist, const float* mf_max_dist, const uint8_t* mp_desc,
+                            const int* mp_obs, const uint8_t* kp_claimed, float th, float nnratio, float viewingCosLimit, int* local_match,
+                            uint8_t* in_view, float* proj, int* level, float* view_cos) {
+  const KeyPoint* keysUn = (const KeyPoint*)keysUn_;
+  FrameGrid G;
+  G.N = N;
+  G.keysUn = keysUn;
+  G.mnMinX = minX; G.mnMaxX = maxX; G.mnMinY = minY; G.mnMaxY = maxY;
+  G.build();
+  auto at = [](const double* T, int r, int c) { return T[c * 4 + r]; };
+  double Rcw[3][3], tcw[3], Ow[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) Rcw[i][j] = at(Tcw_cm, i, j);
+    tcw[i] = at(Tcw_cm, i, 3);
+  }
+  // Frame::UpdatePoseMatrices: mOw = -mRcw.transpose() * mtcw
+  for (int i = 0; i < 3; i++) Ow[i] = (-Rcw[0][i]) * tcw[0] + (-Rcw[1][i]) * tcw[1] + (-Rcw[2][i]) * tcw[2];
+  for (int i = 0; i < N; i++) local_match[i] = -1;
+  // ---- isInFrustum
+  for (int i = 0; i < M; i++) {
+    in_view[i] = 0;
+    proj[3 * i] = proj[3 * i + 1] = proj[3 * i + 2] = 0;
+    level[i] = 0;
+    view_cos[i] = 0;
+    if (!cand[i]) continue;
+    const double* P = Xw + 3 * i;
+    double Pc[3];
+    for (int r = 0; r < 3; r++) Pc[r] = (Rcw[r][0] * P[0] + Rcw[r][1] * P[1] + Rcw[r][2] * P[2]) + tcw[r];
+    const double PcX = Pc[0], PcY = Pc[1], PcZ = Pc[2];
+    if (PcZ < 0.0) continue;
+    const float invz = 1.0f / PcZ;
+    const float u = fx * PcX * invz + cx;
+    const float v = fy * PcY * invz + cy;
+    if (u < minX || u > maxX) continue;
+    if (v < minY || v > maxY) continue;
+    const float maxDistance = max_dist[i];
+    const float minDistance = min_dist[i];
+    const double PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+    const float dist = std::sqrt((PO[0] * PO[0] + PO[1] * PO[1]) + PO[2] * PO[2]);
+    if (dist < minDistance || dist > maxDistance) continue;
+    const double* Pn = normal + 3 * i;
+    const float viewCos = ((PO[0] * Pn[0] + PO[1] * Pn[1]) + PO[2] * Pn[2]) / dist;
+    if (viewCos < viewingCosLimit) continue;
+    // MapPoint::PredictScale
+    const float ratio = mf_max_dist[i] / dist;
+    int nScale = std::ceil(std::log(ratio) / logScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nLevels) nScale = nLevels - 1;
+    in_view[i] = 1;
+    proj[3 * i] = u;
+    proj[3 * i + 2] = u - mbf * invz;
+    proj[3 * i + 1] = v;
+    level[i] = nScale;
+    view_cos[i] = viewCos;
+  }
+  // ---- SearchByProjection(F, vpMapPoints, th)
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  for (int iMP = 0; iMP < M; iMP++) {
+    if (!in_view[iMP]) continue;   // mbTrackInView (isBad points never reach isInFrustum here)
+    const int nPredictedLevel = level[iMP];
+    float r = view_cos[iMP] > 0.998 ? 2.5 : 4.0;   // RadiusByViewingCos
+    if (bFactor) r *= th;
+    const std::vector<size_t> vIndices =
+        G.GetFeaturesInArea(proj[3 * iMP], proj[3 * iMP + 1], r * scaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+    if (vIndices.empty()) continue;
+    const uint8_t* MPdescriptor = mp_desc + 32 * iMP;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (size_t k = 0; k < vIndices.size(); k++) {
+      const size_t idx = vIndices[k];
+      if (local_match[idx] >= 0) {
+        if (mp_obs[local_match[idx]] > 0) continue;
+      } else if (kp_claimed && kp_claimed[idx]) {
+        continue;
+      }
+      if (uRight && uRight[idx] > 0) {
+        const float er = fabs(proj[3 * iMP + 2] - uRight[idx]);
+        if (er > r * scaleFactors[nPredictedLevel]) continue;
+      }
+      const int dist = DescriptorDistance(MPdescriptor, desc + 32 * idx);
+      if (dist < bestDist) {
+        bestDist2 = bestDist;
+        bestDist = dist;
+        bestLevel2 = bestLevel;
+        bestLevel = keysUn[idx].octave;
+        bestIdx = idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = keysUn[idx].octave;
+        bestDist2 = dist;
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+      local_match[bestIdx] = iMP;
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
 // Frame::ComputeStereoFromRGBD -- src/Frame.cc:399-417.  imDepth.at<float>(v, u) takes int arguments:
 // the float keypoint coordinates are truncated.  depth: CV_32F image with `stride` floats per row.
 void orc_stereo_from_rgbd(int N, const void* keys_, const void* keysUn_, const float* depth, int stride, float mbf, float* uRight,

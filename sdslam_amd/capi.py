@@ -385,6 +385,45 @@ class Tracker:
         _check(self.L.sd_track_get_stereo(self.h, frame0, n, _p(u), _p(d), self.cap))
         return u, d
 
+    def set_local(self, frame0, pts_list, kp_claimed=None):
+        """pts_list: per frame dict(cand, Xw, normal, min_dist, max_dist, mf_max_dist, desc, obs) (TrackLocalMap's points)."""
+        n, M = len(pts_list), self.M
+        nl = np.array([len(p["cand"]) for p in pts_list], np.int32)
+
+        def pad(key, shape, dt):
+            a = np.zeros((n,) + shape, dt)
+            for i, p in enumerate(pts_list):
+                v = np.asarray(p[key], dt)
+                a[i, :len(v)] = v
+            return a
+        cand, Xw, nr = pad("cand", (M,), np.uint8), pad("Xw", (M, 3), np.float64), pad("normal", (M, 3), np.float64)
+        mn, mx, mf = pad("min_dist", (M,), np.float32), pad("max_dist", (M,), np.float32), pad("mf_max_dist", (M,), np.float32)
+        md, ob = pad("desc", (M, 32), np.uint8), pad("obs", (M,), np.int32)
+        kc = None
+        if kp_claimed is not None:
+            kc = np.zeros((n, self.cap), np.uint8)
+            for i, k in enumerate(kp_claimed):
+                kc[i, :len(k)] = k
+        self.L.sd_track_set_local.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 10
+        _check(self.L.sd_track_set_local(self.h, frame0, n, _p(nl), _p(cand), _p(Xw), _p(nr), _p(mn), _p(mx), _p(mf), _p(md), _p(ob),
+                                         _p(kc) if kc is not None else None))
+
+    def match_local(self, n_frames, th=1.0, nnratio=0.8, cos_limit=0.5):
+        self.L.sd_track_match_local.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]
+        _check(self.L.sd_track_match_local(self.h, n_frames, float(th), float(nnratio), float(cos_limit)))
+
+    def get_local(self, frame0, n):
+        M = self.M
+        lm = np.zeros((n, self.cap), np.int32)
+        nm = np.zeros(n, np.int32)
+        iv = np.zeros((n, M), np.uint8)
+        pr = np.zeros((n, M, 3), np.float32)
+        lv = np.zeros((n, M), np.int32)
+        cs = np.zeros((n, M), np.float32)
+        self.L.sd_track_get_local.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        _check(self.L.sd_track_get_local(self.h, frame0, n, _p(lm), self.cap, _p(nm), _p(iv), _p(pr), _p(lv), _p(cs)))
+        return dict(match=lm, n=nm, in_view=iv.astype(bool), proj=pr, level=lv, cos=cs)
+
     def align(self, n_frames, mode=0):
         _check(self.L.sd_track_align(self.h, n_frames, mode))
 

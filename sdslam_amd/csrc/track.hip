@@ -9,6 +9,7 @@
 //                                                 -> sd_track_pnp
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -30,6 +31,7 @@ struct sd_track {
   float* d_sf = nullptr;
   float* d_inv_sf = nullptr;
   float* d_sigma2 = nullptr;
+  float* d_scale_thr = nullptr;   // MapPoint::PredictScale breakpoints (see k_match_local)
   std::vector<void*> allocs;
   // The tracking kernels (align, match, PnP: latency-bound, few waves) run on their own stream, so
   // the extraction of the next batch on cur->stream overlaps them; `cur` is double-buffered
@@ -106,6 +108,23 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.pnp_scratch, B * K * 12));
   A(dalloc(h, &tb.pnp_pts, B * K * 6));
   A(dalloc(h, &tb.pnp_kpidx, B * K));
+  A(dalloc(h, &tb.lm_cand, B * M));
+  A(dalloc(h, &tb.lm_Xw, B * M * 3));
+  A(dalloc(h, &tb.lm_normal, B * M * 3));
+  A(dalloc(h, &tb.lm_min, B * M));
+  A(dalloc(h, &tb.lm_max, B * M));
+  A(dalloc(h, &tb.lm_mfmax, B * M));
+  A(dalloc(h, &tb.lm_desc, B * M * 32));
+  A(dalloc(h, &tb.lm_obs, B * M));
+  A(dalloc(h, &tb.lm_n, B));
+  A(dalloc(h, &tb.lm_kclaim, B * K));
+  A(dalloc(h, &tb.lm_inview, B * M));
+  A(dalloc(h, &tb.lm_proj, B * M * 3));
+  A(dalloc(h, &tb.lm_level, B * M));
+  A(dalloc(h, &tb.lm_cos, B * M));
+  A(dalloc(h, &tb.lm_match, B * K));
+  A(dalloc(h, &tb.lm_nmatch, B));
+  A(dalloc(h, &h->d_scale_thr, (size_t)SD_MAX_LEVELS));
   A(dalloc(h, &h->d_sf, (size_t)cur->nlevels));
   A(dalloc(h, &h->d_inv_sf, (size_t)cur->nlevels));
   A(dalloc(h, &h->d_sigma2, (size_t)cur->nlevels));
@@ -119,6 +138,27 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
     hipError_t e = hipMemcpy(h->d_sf, cur->hp.sf.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_inv_sf, cur->hp.inv_sf.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_sigma2, cur->hp.sigma2.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      // MapPoint::PredictScale (src/MapPoint.cc:371-385): nScale = ceil(log(ratio) / mfLogScaleFactor), float overloads,
+      // mfLogScaleFactor = log(mfScaleFactor) (src/Frame.cc:80).  thr[n] = smallest float ratio that reaches level n,
+      // by bisection over the float bit patterns with THIS host's libm (the function is monotone).
+      float thr[SD_MAX_LEVELS];
+      const float Lsf = logf(cur->scaleFactor);
+      thr[0] = 0.f;
+      for (int n = 1; n < SD_MAX_LEVELS; n++) {
+        uint32_t lo = 1, hi = 0x7f800000u;   // hi = +inf: never reached
+        while (lo < hi) {
+          const uint32_t mid = lo + (hi - lo) / 2;
+          float r;
+          memcpy(&r, &mid, 4);
+          const int ns = (int)ceilf(logf(r) / Lsf);
+          if (ns >= n) hi = mid;
+          else lo = mid + 1;
+        }
+        memcpy(&thr[n], &lo, 4);
+      }
+      e = hipMemcpy(h->d_scale_thr, thr, sizeof(thr), hipMemcpyHostToDevice);
+    }
     for (int r = 0; r < sd_track::kRing && e == hipSuccess; r++)
       for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
     if (e == hipSuccess) {
@@ -273,6 +313,63 @@ int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori)
   if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[3], s)); h->ev_calls[1]++; }
   if (rc == SD_OK) rc = mark_reads(h, false);
   return rc;
+}
+
+// TrackLocalMap's search.  Local map points of every frame, flattened in mvpLocalMapPoints order.
+int sd_track_set_local(sd_track* h, int frame0, int n_frames, const int32_t* n_local, const uint8_t* cand, const double* Xw,
+                       const double* normal, const float* min_dist, const float* max_dist, const float* mf_max_dist, const uint8_t* desc,
+                       const int32_t* obs, const uint8_t* kp_claimed) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(n_local && cand && Xw && normal && min_dist && max_dist && mf_max_dist && desc && obs, SD_ERR_INVALID_ARG, "NULL argument");
+  const size_t M = h->max_points, o = (size_t)frame0, K = h->kp_cap;
+  for (int f = 0; f < n_frames; f++) SD_REQUIRE(n_local[f] >= 0 && n_local[f] <= h->max_points, SD_ERR_CAPACITY, "n_local exceeds max_points");
+  hipStream_t s = h->cur->stream;
+  const TrackBuffers& tb = h->tb;
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_n + o, n_local, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_cand + o * M, cand, n_frames * M, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_Xw + o * M * 3, Xw, n_frames * M * 3 * 8, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_normal + o * M * 3, normal, n_frames * M * 3 * 8, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_min + o * M, min_dist, n_frames * M * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_max + o * M, max_dist, n_frames * M * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_mfmax + o * M, mf_max_dist, n_frames * M * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_desc + o * M * 32, desc, n_frames * M * 32, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_obs + o * M, obs, n_frames * M * 4, hipMemcpyHostToDevice, s));
+  if (kp_claimed) SD_HIP_CHECK(hipMemcpyAsync(tb.lm_kclaim + o * K, kp_claimed, n_frames * K, hipMemcpyHostToDevice, s));
+  else SD_HIP_CHECK(hipMemsetAsync(tb.lm_kclaim + o * K, 0, n_frames * K, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
+}
+
+// Frame::isInFrustum for every candidate + ORBmatcher::SearchByProjection(F, vpMapPoints, th) with mfNNratio = nnratio,
+// at the frames' current poses (sd_track_set_poses / the ImageAlign result)
+int sd_track_match_local(sd_track* h, int n_frames, float th, float nnratio, float viewing_cos_limit) {
+  int rc = check_ready(h, n_frames);
+  if (rc != SD_OK) return rc;
+  hipStream_t s = h->pnp_stream;
+  rc = wait_inputs(h, false);
+  if (rc != SD_OK) return rc;
+  rc = launch_match_local(h->cur, h->tb, h->cam, h->d_sf, h->d_scale_thr, h->cur->nlevels, n_frames, th, nnratio, viewing_cos_limit, s);
+  if (rc == SD_OK) rc = mark_reads(h, false);
+  return rc;
+}
+
+int sd_track_get_local(sd_track* h, int frame0, int n_frames, int32_t* local_match, int cap, int32_t* n_matches, uint8_t* in_view,
+                       float* proj3, int32_t* level, float* view_cos) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(!local_match || cap >= h->kp_cap, SD_ERR_CAPACITY, "cap smaller than the keypoint capacity");
+  hipStream_t s = h->cur->stream;
+  const size_t M = h->max_points, o = frame0, n = n_frames;
+  const TrackBuffers& tb = h->tb;
+  if (local_match)
+    SD_HIP_CHECK(hipMemcpy2DAsync(local_match, (size_t)cap * 4, tb.lm_match + o * h->kp_cap, (size_t)h->kp_cap * 4, (size_t)h->kp_cap * 4, n_frames,
+                                  hipMemcpyDeviceToHost, s));
+  if (n_matches) SD_HIP_CHECK(hipMemcpyAsync(n_matches, tb.lm_nmatch + o, n * 4, hipMemcpyDeviceToHost, s));
+  if (in_view) SD_HIP_CHECK(hipMemcpyAsync(in_view, tb.lm_inview + o * M, n * M, hipMemcpyDeviceToHost, s));
+  if (proj3) SD_HIP_CHECK(hipMemcpyAsync(proj3, tb.lm_proj + o * M * 3, n * M * 12, hipMemcpyDeviceToHost, s));
+  if (level) SD_HIP_CHECK(hipMemcpyAsync(level, tb.lm_level + o * M, n * M * 4, hipMemcpyDeviceToHost, s));
+  if (view_cos) SD_HIP_CHECK(hipMemcpyAsync(view_cos, tb.lm_cos + o * M, n * M * 4, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
 }
 
 // CurrentFrame.mvuRight supplied by the caller (stereo) -- [n_frames][kp_cap] floats, -1 = none

@@ -41,6 +41,24 @@ struct TrackBuffers {
   double* pnp_scratch;   // [B][kp_cap*12] EPnP per-correspondence work arrays (pws, us, alphas, pcs)
   float* pnp_pts;        // [B][kp_cap][6] gathered correspondences {u, v, X, Y, Z, maxErr}
   uint16_t* pnp_kpidx;   // [B][kp_cap] mvKeyPointIndices
+  // local map (TrackLocalMap's search); capacity M like the last-frame arrays
+  uint8_t* lm_cand;      // [B][M]   point reaches isInFrustum (not bad, not already seen in this frame)
+  double* lm_Xw;         // [B][M][3]
+  double* lm_normal;     // [B][M][3] GetNormal()
+  float* lm_min;         // [B][M]   GetMinDistanceInvariance()
+  float* lm_max;         // [B][M]   GetMaxDistanceInvariance()
+  float* lm_mfmax;       // [B][M]   mfMaxDistance
+  uint8_t* lm_desc;      // [B][M][32]
+  int32_t* lm_obs;       // [B][M]
+  int32_t* lm_n;         // [B]
+  uint8_t* lm_kclaim;    // [B][kp_cap] keypoint already holds a point with Observations() > 0
+  // outputs
+  uint8_t* lm_inview;    // [B][M]   mbTrackInView
+  float* lm_proj;        // [B][M][3] mTrackProjX, mTrackProjY, mTrackProjXR
+  int32_t* lm_level;     // [B][M]   mnTrackScaleLevel
+  float* lm_cos;         // [B][M]   mTrackViewCos
+  int32_t* lm_match;     // [B][kp_cap] index into the local-map arrays or -1
+  int32_t* lm_nmatch;    // [B]
 };
 
 struct TrackCam {
@@ -62,6 +80,8 @@ int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, c
                  const float* d_sf, int n_frames, int mode, hipStream_t s);
 int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, int n_frames, float th,
                  int mono, int check_ori, hipStream_t s);
+int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, const float* d_scale_thr,
+                       int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s);
 int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_depth, int w, int h,
                              int stride_elems, size_t frame_stride_elems, int n_frames, hipStream_t s);
 int read_pnp_prof(unsigned long long* out32, int reset);

@@ -46,55 +46,54 @@ struct MatchGeom {   // what every per-point evaluation needs (uniform over the 
 //   mode 1: writes key = dist << 22 | order-in-vIndices2 << 11 | keypoint index to list[0 .. count)
 //   mode 2: returns this lane's minimum key over the candidates not claimed by a point with observations
 // *seq_total = entries of the searched cells (keys carry 11 bits of order).
+// Candidates of one search window: GetFeaturesInArea(u, v, radius, minLevel, maxLevel) (src/Frame.cc:271-321) in
+// the reference's order, then the stereo gate |ur - mvuRight[idx]| <= radius for keypoints with a right
+// coordinate (src/ORBmatcher.cc:76-80, 1020-1025) and, in MODE 2, the "already holds a map point with
+// Observations() > 0" gate.  All 64 lanes call.
+//   mode 0: returns the number of candidates (wave-uniform)
+//   mode 1: writes key = dist << 22 | order-in-vIndices << 11 | keypoint index to list[0 .. count)
+//   mode 2: returns this lane's minimum key over the unclaimed candidates
+// *seq_total = entries of the searched cells (keys carry 11 bits of order).
+struct MatchLds {
+  const uint32_t* s_key;      // sorted (cell << 11 | index)
+  const uint16_t* s_cstart;   // first sorted position of every cell
+  const int16_t* s_match;     // map point assigned to a keypoint in this call, or -1
+  const uint32_t* s_obs;      // bit m: map point m has Observations() > 0
+  const uint32_t* s_kclaim;   // bit idx: keypoint idx already held such a point before the call (may be null)
+};
+
 template <int MODE>
-__device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
-                                                const double* __restrict__ Xw, const uint8_t* __restrict__ mp_desc,
-                                                const int32_t* __restrict__ l_oct, const float* __restrict__ uright,
-                                                const uint32_t* s_key, const uint16_t* s_cstart, const int16_t* s_match,
-                                                const uint32_t* s_obs, const MatchGeom& G, const TrackCam& cam,
-                                                const float* __restrict__ sf, uint32_t* list, int lane, unsigned long long lt,
-                                                int* seq_total) {
-  const double xw = Xw[(size_t)i * 3], yw = Xw[(size_t)i * 3 + 1], zw = Xw[(size_t)i * 3 + 2];
-  const double X = (G.R[0][0] * xw + G.R[0][1] * yw + G.R[0][2] * zw) + G.t[0];
-  const double Y = (G.R[1][0] * xw + G.R[1][1] * yw + G.R[1][2] * zw) + G.t[1];
-  const double Z = (G.R[2][0] * xw + G.R[2][1] * yw + G.R[2][2] * zw) + G.t[2];
-  const float xc = (float)X, yc = (float)Y;
-  const float invzc = (float)(1.0 / Z);
+__device__ __forceinline__ uint32_t match_window(float u, float v, float radius, int minLevel, int maxLevel, float ur,
+                                                 const uint8_t* __restrict__ dmp /* 32-byte map point descriptor */,
+                                                 const sd_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                 const float* __restrict__ uright, const MatchLds& S, const TrackCam& cam, float invW,
+                                                 float invH, uint32_t* list, int lane, unsigned long long lt, int* seq_total,
+                                                 long long above = -1 /* MODE 2: only keys greater than this */) {
   uint32_t best = 0x7FFFFFFFu;
   *seq_total = 0;
-  if (invzc < 0) return MODE == 2 ? best : 0;
-  const float u = cam.ffx * xc * invzc + cam.fcx;
-  const float v = cam.ffy * yc * invzc + cam.fcy;
-  if (u < cam.min_x || u > cam.max_x) return MODE == 2 ? best : 0;
-  if (v < cam.min_y || v > cam.max_y) return MODE == 2 ? best : 0;
-  const int nLastOctave = l_oct[i];
-  const float radius = G.th * sf[nLastOctave];
-  const int minLevel = G.bForward ? nLastOctave : (G.bBackward ? 0 : nLastOctave - 1);
-  const int maxLevel = G.bForward ? -1 : (G.bBackward ? nLastOctave : nLastOctave + 1);
-  // GetFeaturesInArea(u, v, radius, minLevel, maxLevel)
-  const int nMinCellX = max(0, (int)floorf((u - cam.min_x - radius) * G.invW));
+  const int nMinCellX = max(0, (int)floorf((u - cam.min_x - radius) * invW));
   if (nMinCellX >= GRID_COLS) return MODE == 2 ? best : 0;
-  const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((u - cam.min_x + radius) * G.invW));
+  const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((u - cam.min_x + radius) * invW));
   if (nMaxCellX < 0) return MODE == 2 ? best : 0;
-  const int nMinCellY = max(0, (int)floorf((v - cam.min_y - radius) * G.invH));
+  const int nMinCellY = max(0, (int)floorf((v - cam.min_y - radius) * invH));
   if (nMinCellY >= GRID_ROWS) return MODE == 2 ? best : 0;
-  const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((v - cam.min_y + radius) * G.invH));
+  const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((v - cam.min_y + radius) * invH));
   if (nMaxCellY < 0) return MODE == 2 ? best : 0;
   const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
   unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
   if (MODE != 0) {
-    const unsigned long long* dm = (const unsigned long long*)(mp_desc + (size_t)i * 32);
+    const unsigned long long* dm = (const unsigned long long*)dmp;
     d0 = dm[0]; d1 = dm[1]; d2 = dm[2]; d3 = dm[3];
   }
   int seq0 = 0, w = 0;
   for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-    const int a = s_cstart[ix * GRID_ROWS + nMinCellY], b = s_cstart[ix * GRID_ROWS + nMaxCellY + 1];
+    const int a = S.s_cstart[ix * GRID_ROWS + nMinCellY], b = S.s_cstart[ix * GRID_ROWS + nMaxCellY + 1];
     for (int e0 = a; e0 < b; e0 += 64) {
       const int e = e0 + lane;
       bool okc = false;
       int idx = 0;
       if (e < b) {
-        idx = s_key[e] & 2047;
+        idx = S.s_key[e] & 2047;
         const sd_keypoint kp = kps[idx];
         okc = true;
         if (bCheckLevels) {
@@ -105,41 +104,69 @@ __device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __rest
         if (!(fabsf(distx) < radius && fabsf(disty) < radius)) okc = false;
         if (okc) {
           const float ur2 = uright[idx];
-          if (ur2 > 0) {   // stereo consistency gate (src/ORBmatcher.cc:1020-1025)
-            const float ur = u - cam.bf * invzc;
+          if (ur2 > 0) {
             const float er = fabsf(ur - ur2);
             if (er > radius) okc = false;
           }
         }
         if (MODE == 2 && okc) {
-          const int m = s_match[idx];
-          if (m >= 0 && ((s_obs[m >> 5] >> (m & 31)) & 1u)) okc = false;   // already holds a point with Observations() > 0
+          const int m = S.s_match[idx];
+          if (m >= 0 && ((S.s_obs[m >> 5] >> (m & 31)) & 1u)) okc = false;
+          if (S.s_kclaim && ((S.s_kclaim[idx >> 5] >> (idx & 31)) & 1u) && m < 0) okc = false;
         }
       }
       if (MODE == 0) {
         w += __popcll(__ballot(okc));
-      } else if (okc) {
-        const unsigned long long* dk = (const unsigned long long*)(desc + (size_t)idx * 32);
-        const int dist = __popcll(dk[0] ^ d0) + __popcll(dk[1] ^ d1) + __popcll(dk[2] ^ d2) + __popcll(dk[3] ^ d3);
-        // NB: candidates failing the window test do not advance the reference's vIndices2 order
-        // relative to each other, so the sorted-array position is a valid order key
-        const uint32_t key = ((uint32_t)dist << 22) | ((uint32_t)(seq0 + (e - a)) << 11) | (uint32_t)idx;
-        if (MODE == 2) best = min(best, key);
-      }
-      if (MODE == 1) {
-        const unsigned long long bal = __ballot(okc);
+      } else {
+        uint32_t key = 0;
         if (okc) {
           const unsigned long long* dk = (const unsigned long long*)(desc + (size_t)idx * 32);
           const int dist = __popcll(dk[0] ^ d0) + __popcll(dk[1] ^ d1) + __popcll(dk[2] ^ d2) + __popcll(dk[3] ^ d3);
-          list[w + __popcll(bal & lt)] = ((uint32_t)dist << 22) | ((uint32_t)(seq0 + (e - a)) << 11) | (uint32_t)idx;
+          // NB: candidates failing the window test do not advance the reference's vIndices order
+          // relative to each other, so the sorted-array position is a valid order key
+          key = ((uint32_t)dist << 22) | ((uint32_t)(seq0 + (e - a)) << 11) | (uint32_t)idx;
+          if (MODE == 2 && (long long)key > above) best = min(best, key);
         }
-        w += __popcll(bal);
+        if (MODE == 1) {
+          const unsigned long long bal = __ballot(okc);
+          if (okc) list[w + __popcll(bal & lt)] = key;
+          w += __popcll(bal);
+        }
       }
     }
     seq0 += b - a;
   }
   *seq_total = seq0;
   return MODE == 2 ? best : (uint32_t)w;
+}
+
+// a16 / a17: projection of last-frame point i (src/ORBmatcher.cc:974-1004) and its window
+template <int MODE>
+__device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                const double* __restrict__ Xw, const uint8_t* __restrict__ mp_desc,
+                                                const int32_t* __restrict__ l_oct, const float* __restrict__ uright,
+                                                const MatchLds& S, const MatchGeom& G, const TrackCam& cam,
+                                                const float* __restrict__ sf, uint32_t* list, int lane, unsigned long long lt,
+                                                int* seq_total) {
+  const double xw = Xw[(size_t)i * 3], yw = Xw[(size_t)i * 3 + 1], zw = Xw[(size_t)i * 3 + 2];
+  const double X = (G.R[0][0] * xw + G.R[0][1] * yw + G.R[0][2] * zw) + G.t[0];
+  const double Y = (G.R[1][0] * xw + G.R[1][1] * yw + G.R[1][2] * zw) + G.t[1];
+  const double Z = (G.R[2][0] * xw + G.R[2][1] * yw + G.R[2][2] * zw) + G.t[2];
+  const float xc = (float)X, yc = (float)Y;
+  const float invzc = (float)(1.0 / Z);
+  *seq_total = 0;
+  if (invzc < 0) return MODE == 2 ? 0x7FFFFFFFu : 0;
+  const float u = cam.ffx * xc * invzc + cam.fcx;
+  const float v = cam.ffy * yc * invzc + cam.fcy;
+  if (u < cam.min_x || u > cam.max_x) return MODE == 2 ? 0x7FFFFFFFu : 0;
+  if (v < cam.min_y || v > cam.max_y) return MODE == 2 ? 0x7FFFFFFFu : 0;
+  const int nLastOctave = l_oct[i];
+  const float radius = G.th * sf[nLastOctave];
+  const int minLevel = G.bForward ? nLastOctave : (G.bBackward ? 0 : nLastOctave - 1);
+  const int maxLevel = G.bForward ? -1 : (G.bBackward ? nLastOctave : nLastOctave + 1);
+  const float ur = u - cam.bf * invzc;
+  return match_window<MODE>(u, v, radius, minLevel, maxLevel, ur, mp_desc + (size_t)i * 32, kps, desc, uright, S, cam, G.invW, G.invH, list,
+                            lane, lt, seq_total);
 }
 
 // Dynamic LDS layout (KP2 = power of two >= keypoint capacity, MP = max_points):
@@ -250,6 +277,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
   }
   __syncthreads();
 
+  const MatchLds SL = {s_key, s_cstart, s_match, s_obs, nullptr};
   // ---- phase 1 (all waves, one wave per last-frame point): candidate keys into the LDS list.
   // s_pt[i] = 0 (nothing to do) | offset << 16 | count | 0xFFFFFFFF (list full: evaluate in phase 2)
   for (int i0 = 0; i0 < n_last; i0 += MT_WAVES) {
@@ -258,8 +286,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
     uint32_t pc = 0;
     if (valid[i]) {
       int seq = 0;
-      const int cnt = (int)match_point<0>(i, kps, desc, Xw, mp_desc, l_oct, uright, s_key, s_cstart, s_match, s_obs, G, cam, sf, nullptr, lane,
-                                          lt, &seq);
+      const int cnt = (int)match_point<0>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, nullptr, lane, lt, &seq);
       if (cnt > 0) {
         int off = 0;
         if (lane == 0) off = atomicAdd(s_nlist, cnt);
@@ -267,7 +294,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
         if (off + cnt > MT_LIST_CAP || seq >= 2048 || cnt > 0xffff) {
           pc = 0xFFFFFFFFu;
         } else {
-          match_point<1>(i, kps, desc, Xw, mp_desc, l_oct, uright, s_key, s_cstart, s_match, s_obs, G, cam, sf, s_list + off, lane, lt, &seq);
+          match_point<1>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, s_list + off, lane, lt, &seq);
           pc = ((uint32_t)off << 16) | (uint32_t)cnt;
         }
       }
@@ -295,7 +322,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
       }
     } else {
       int seq = 0;
-      best = match_point<2>(i, kps, desc, Xw, mp_desc, l_oct, uright, s_key, s_cstart, s_match, s_obs, G, cam, sf, nullptr, lane, lt, &seq);
+      best = match_point<2>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, nullptr, lane, lt, &seq);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
@@ -355,6 +382,256 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
   if (lane == 0) tb.n_matches[f] = nmatches;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_match_local: TrackLocalMap's search for one frame per workgroup.
+//   Frame::isInFrustum            src/Frame.cc:215-269   (one thread per local map point)
+//   MapPoint::PredictScale        src/MapPoint.cc:371-385: nScale = clamp(ceil(log(ratio) / logScaleFactor)) is a
+//                                 monotone step function of the float `ratio`; its breakpoints scale_thr[n] (smallest
+//                                 ratio that reaches level n) are found on the host with the host libm, so the device
+//                                 needs no log() and agrees with the reference's libm by construction
+//   ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)   src/ORBmatcher.cc:43-126
+// Same two phases as k_match; the per-point result needs the two smallest keys (best / second best for the
+// mfNNratio test), which are the reference's bestDist / bestDist2 because both are updated with strict `<` in
+// vIndices order.
+// Dynamic LDS: the k_match layout + u32 s_kclaim[KP2/32] + u8 s_koct[KP2].
+__global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
+                                                                const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
+                                                                const float* __restrict__ sf, const float* __restrict__ scale_thr,
+                                                                int nlevels, float th, float nnratio, float cos_limit, int KP2) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int MP = tb.max_points;
+  uint32_t* s_key = (uint32_t*)smem;
+  uint32_t* s_list = s_key + KP2;
+  uint32_t* s_pt = s_list + MT_LIST_CAP;
+  uint32_t* s_obs = s_pt + MP;
+  uint32_t* s_kclaim = s_obs + ((MP + 31) >> 5);
+  int16_t* s_match = (int16_t*)(s_kclaim + (KP2 >> 5));
+  uint16_t* s_cstart = (uint16_t*)(s_match + KP2);
+  uint8_t* s_koct = (uint8_t*)(s_cstart + GRID_COLS * GRID_ROWS + 2);
+  int* s_nlist = (int*)(((uintptr_t)(s_koct + KP2) + 3) & ~(uintptr_t)3);
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = 64 * MT_WAVES;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int cap = tb.kp_cap, M = MP;
+  const sd_keypoint* kps = kps_all + (size_t)f * cap;
+  const uint8_t* desc = desc_all + (size_t)f * cap * 32;
+  const int N = min(nkp_all[f], min(cap, KP2));
+  const float invW = (float)GRID_COLS / (float)(cam.max_x - cam.min_x);
+  const float invH = (float)GRID_ROWS / (float)(cam.max_y - cam.min_y);
+  const int n_loc = min(tb.lm_n[f], M);
+  const uint8_t* cand = tb.lm_cand + (size_t)f * M;
+  const double* Xw = tb.lm_Xw + (size_t)f * M * 3;
+  const double* nrm = tb.lm_normal + (size_t)f * M * 3;
+  const float* dmin = tb.lm_min + (size_t)f * M;
+  const float* dmax = tb.lm_max + (size_t)f * M;
+  const float* mfmax = tb.lm_mfmax + (size_t)f * M;
+  const uint8_t* mp_desc = tb.lm_desc + (size_t)f * M * 32;
+  const int32_t* l_obs = tb.lm_obs + (size_t)f * M;
+  const uint8_t* kclaim = tb.lm_kclaim + (size_t)f * cap;
+  const float* uright = tb.uright + (size_t)f * cap;
+  uint8_t* o_inview = tb.lm_inview + (size_t)f * M;
+  float* o_proj = tb.lm_proj + (size_t)f * M * 3;
+  int32_t* o_level = tb.lm_level + (size_t)f * M;
+  float* o_cos = tb.lm_cos + (size_t)f * M;
+
+  // ---- grid (as in k_match) + claim flags + octaves
+  for (int i = tid; i < KP2; i += NT) {
+    uint32_t key = 0xFFFFFFFFu;
+    int oct = 0;
+    if (i < N) {
+      const sd_keypoint kp = kps[i];
+      oct = kp.octave;
+      const int posX = (int)roundf((kp.x - cam.min_x) * invW);
+      const int posY = (int)roundf((kp.y - cam.min_y) * invH);
+      if (!(posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS)) key = ((uint32_t)(posX * GRID_ROWS + posY) << 11) | (uint32_t)i;
+    }
+    s_key[i] = key;
+    s_koct[i] = (uint8_t)oct;
+    s_match[i] = -1;
+  }
+  for (int w = tid; w < (KP2 >> 5); w += NT) {
+    uint32_t bits = 0;
+    for (int k = 0; k < 32; k++) {
+      const int i = w * 32 + k;
+      if (i < N && kclaim[i]) bits |= 1u << k;
+    }
+    s_kclaim[w] = bits;
+  }
+  for (int w = tid; w < ((MP + 31) >> 5); w += NT) {
+    uint32_t bits = 0;
+    for (int k = 0; k < 32; k++) {
+      const int m = w * 32 + k;
+      if (m < n_loc && l_obs[m] > 0) bits |= 1u << k;
+    }
+    s_obs[w] = bits;
+  }
+  if (tid == 0) *s_nlist = 0;
+  __syncthreads();
+  for (int k = 2; k <= KP2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < KP2; i += NT) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          uint32_t a = s_key[i], b = s_key[ixj];
+          bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            s_key[i] = b;
+            s_key[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (int c = tid; c <= GRID_COLS * GRID_ROWS; c += NT) {
+    const uint32_t target = (uint32_t)c << 11;
+    int lo = 0, hi = KP2;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (s_key[mid] < target) lo = mid + 1;
+      else hi = mid;
+    }
+    s_cstart[c] = (uint16_t)lo;
+  }
+  // ---- isInFrustum, one thread per point
+  {
+    const double* Tc = tb.Tcur + (size_t)f * 16;   // column-major
+    double R[3][3], t[3], Ow[3];
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) R[r][c] = Tc[c * 4 + r];
+      t[r] = Tc[12 + r];
+    }
+    for (int i = 0; i < 3; i++) Ow[i] = (-R[0][i]) * t[0] + (-R[1][i]) * t[1] + (-R[2][i]) * t[2];   // mOw = -Rcw^T tcw
+    for (int i = tid; i < M; i += NT) {
+      uint8_t inview = 0;
+      float pu = 0, pv = 0, pxr = 0, vc = 0;
+      int lvl = 0;
+      if (i < n_loc && cand[i]) {
+        const double P0 = Xw[(size_t)i * 3], P1 = Xw[(size_t)i * 3 + 1], P2 = Xw[(size_t)i * 3 + 2];
+        const double PcX = (R[0][0] * P0 + R[0][1] * P1 + R[0][2] * P2) + t[0];
+        const double PcY = (R[1][0] * P0 + R[1][1] * P1 + R[1][2] * P2) + t[1];
+        const double PcZ = (R[2][0] * P0 + R[2][1] * P1 + R[2][2] * P2) + t[2];
+        if (!(PcZ < 0.0)) {
+          const float invz = (float)(1.0 / PcZ);                                  // 1.0f / PcZ
+          const float u = (float)((double)cam.ffx * PcX * (double)invz + (double)cam.fcx);
+          const float v = (float)((double)cam.ffy * PcY * (double)invz + (double)cam.fcy);
+          if (!(u < cam.min_x || u > cam.max_x) && !(v < cam.min_y || v > cam.max_y)) {
+            const double PO0 = P0 - Ow[0], PO1 = P1 - Ow[1], PO2 = P2 - Ow[2];
+            const float dist = (float)sqrt((PO0 * PO0 + PO1 * PO1) + PO2 * PO2);
+            if (!(dist < dmin[i] || dist > dmax[i])) {
+              const float viewCos = (float)(((PO0 * nrm[(size_t)i * 3] + PO1 * nrm[(size_t)i * 3 + 1]) + PO2 * nrm[(size_t)i * 3 + 2]) / (double)dist);
+              if (!(viewCos < cos_limit)) {
+                const float ratio = mfmax[i] / dist;
+                int nScale = 0;
+                for (int n = 1; n < nlevels; n++) nScale += (ratio >= scale_thr[n]) ? 1 : 0;   // PredictScale
+                inview = 1;
+                pu = u;
+                pv = v;
+                pxr = u - cam.bf * invz;
+                lvl = nScale;
+                vc = viewCos;
+              }
+            }
+          }
+        }
+      }
+      o_inview[i] = inview;
+      o_proj[(size_t)i * 3] = pu;
+      o_proj[(size_t)i * 3 + 1] = pv;
+      o_proj[(size_t)i * 3 + 2] = pxr;
+      o_level[i] = lvl;
+      o_cos[i] = vc;
+    }
+  }
+  __syncthreads();   // also makes the o_* stores of this workgroup visible to its own later loads
+  const MatchLds SL = {s_key, s_cstart, s_match, s_obs, s_kclaim};
+  const bool bFactor = th != 1.0f;
+  // ---- phase 1: candidate lists
+  for (int i0 = 0; i0 < n_loc; i0 += MT_WAVES) {
+    const int i = i0 + wave;
+    if (i >= n_loc) break;
+    uint32_t pc = 0;
+    if (o_inview[i]) {
+      float r = o_cos[i] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos
+      if (bFactor) r *= th;
+      const int lvl = o_level[i];
+      const float radius = r * sf[lvl];
+      int seq = 0;
+      const int cnt = (int)match_window<0>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], radius, lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
+                                           mp_desc + (size_t)i * 32, kps, desc, uright, SL, cam, invW, invH, nullptr, lane, lt, &seq);
+      if (cnt > 0) {
+        int off = 0;
+        if (lane == 0) off = atomicAdd(s_nlist, cnt);
+        off = __shfl(off, 0);
+        if (off + cnt > MT_LIST_CAP || seq >= 2048 || cnt > 0xffff) {
+          pc = 0xFFFFFFFFu;
+        } else {
+          match_window<1>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], radius, lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
+                          mp_desc + (size_t)i * 32, kps, desc, uright, SL, cam, invW, invH, s_list + off, lane, lt, &seq);
+          pc = ((uint32_t)off << 16) | (uint32_t)cnt;
+        }
+      }
+    }
+    if (lane == 0) s_pt[i] = pc;
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  // ---- phase 2: best / second best over the unclaimed candidates, ratio test, assignment
+  int nmatches = 0;
+  for (int i = 0; i < n_loc; i++) {
+    const uint32_t pc = s_pt[i];
+    if (pc == 0) continue;
+    uint32_t gb, gs;   // the two smallest unclaimed keys of the point (wave-uniform)
+    if (pc != 0xFFFFFFFFu) {
+      uint32_t best = 0x7FFFFFFFu, second = 0x7FFFFFFFu;
+      const int off = pc >> 16, cnt = pc & 0xffff;
+      for (int j = lane; j < cnt; j += 64) {
+        const uint32_t key = s_list[off + j];
+        const int idx = key & 2047;
+        const int m = s_match[idx];
+        const bool claimed = m >= 0 ? (((s_obs[m >> 5] >> (m & 31)) & 1u) != 0) : (((s_kclaim[idx >> 5] >> (idx & 31)) & 1u) != 0);
+        if (!claimed) {
+          if (key < best) { second = best; best = key; }
+          else if (key < second) second = key;
+        }
+      }
+      gb = best;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) gb = min(gb, (uint32_t)__shfl_xor((int)gb, o));
+      gs = (best == gb) ? second : best;   // the lane that holds the best offers its runner-up, the others their best
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) gs = min(gs, (uint32_t)__shfl_xor((int)gs, o));
+    } else {   // candidate list did not fit in LDS: enumerate the window again (best, then the best above it)
+      float r = o_cos[i] > 0.998 ? 2.5f : 4.0f;
+      if (bFactor) r *= th;
+      const int lvl = o_level[i];
+      int seq = 0;
+      gb = match_window<2>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], r * sf[lvl], lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
+                           mp_desc + (size_t)i * 32, kps, desc, uright, SL, cam, invW, invH, nullptr, lane, lt, &seq);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) gb = min(gb, (uint32_t)__shfl_xor((int)gb, o));
+      gs = 0x7FFFFFFFu;
+      if (gb != 0x7FFFFFFFu) {
+        gs = match_window<2>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], r * sf[lvl], lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
+                             mp_desc + (size_t)i * 32, kps, desc, uright, SL, cam, invW, invH, nullptr, lane, lt, &seq, (long long)gb);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gs = min(gs, (uint32_t)__shfl_xor((int)gs, o));
+      }
+    }
+    if (gb == 0x7FFFFFFFu) continue;
+    const int bestDist = gb >> 22, bestIdx = gb & 2047;
+    const int bestDist2 = gs == 0x7FFFFFFFu ? 256 : (int)(gs >> 22);
+    const int bestLevel = s_koct[bestIdx];
+    const int bestLevel2 = gs == 0x7FFFFFFFu ? -1 : (int)s_koct[gs & 2047];
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+      if (lane == 0) s_match[bestIdx] = (int16_t)i;
+      nmatches++;
+    }
+  }
+  int32_t* out = tb.lm_match + (size_t)f * cap;
+  for (int i = lane; i < cap; i += 64) out[i] = i < KP2 ? (int32_t)s_match[i] : -1;
+  if (lane == 0) tb.lm_nmatch[f] = nmatches;
+}
+
 // Frame::ComputeStereoFromRGBD (src/Frame.cc:399-417): d = imDepth.at<float>(kp.pt.y, kp.pt.x) at the
 // DISTORTED keypoint (coordinates truncated to int); mvDepth = d, mvuRight = kpU.pt.x - mbf / d if d > 0.
 __global__ void k_stereo_from_depth(const sd_keypoint* __restrict__ kps, const sd_keypoint* __restrict__ kps_un,
@@ -382,6 +659,20 @@ int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const Tr
                              int stride_elems, size_t frame_stride_elems, int n_frames, hipStream_t s) {
   hipLaunchKernelGGL(k_stereo_from_depth, dim3((tb.kp_cap + 255) / 256, n_frames), dim3(256), 0, s, cur->d_kps,
                      (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam, d_depth, w, h, stride_elems, frame_stride_elems);
+  SD_HIP_CHECK(hipGetLastError());
+  return SD_OK;
+}
+
+int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, const float* d_scale_thr,
+                       int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s) {
+  int KP2 = 64;
+  while (KP2 < tb.kp_cap) KP2 <<= 1;
+  SD_REQUIRE(KP2 <= MT_MAXKP && tb.max_points <= 2048, SD_ERR_CAPACITY, "matcher supports at most 2048 keypoints / map points per frame");
+  const int MP = tb.max_points;
+  const size_t lds = (size_t)KP2 * 4 + MT_LIST_CAP * 4 + (size_t)MP * 4 + (size_t)((MP + 31) >> 5) * 4 + (size_t)(KP2 >> 5) * 4 + (size_t)KP2 * 2 +
+                     (GRID_COLS * GRID_ROWS + 2) * 2 + (size_t)KP2 + 4 + 8;
+  hipLaunchKernelGGL(k_match_local, dim3(n_frames), dim3(64 * MT_WAVES), lds, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_desc,
+                     cur->d_nout, tb, cam, d_sf, d_scale_thr, nlevels, th, nnratio, cos_limit, KP2);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }

@@ -147,3 +147,43 @@ def glibc_rand_stream(n, seed=1):
         if i >= 344:
             out.append(v >> 1)
     return np.array(out, np.int32)
+
+
+def local_map_case(seed, kps, desc, T_cur, n_extra=300, scale_factor=1.2, nlevels=8):
+    """Synthetic TrackLocalMap input for a current frame with keypoints `kps` / descriptors `desc` seen at pose
+    T_cur: one local map point per keypoint (the scene-surface point it sees, descriptor = the keypoint's with a few
+    flipped bits, normal roughly along the viewing ray, distance-invariance interval around the true distance and the
+    keypoint's octave), plus `n_extra` points that fail one of isInFrustum's tests or have no good match (behind the
+    camera, outside the image, too near / far, grazing view, random descriptor).  Returns the dict the oracle and
+    Tracker.set_local take, in a shuffled but deterministic order."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    R, t = T_cur[:3, :3], T_cur[:3, 3]
+    Ow = -R.T @ t
+    n = len(kps)
+    rays = np.stack([(kps["x"].astype(np.float64) - CX) / FX, (kps["y"].astype(np.float64) - CY) / FY, np.ones(n)], -1)
+    Xw = intersect_surface(Ow, rays @ R, 2.0)                                     # world directions = R^T ray
+    PO = Xw - Ow
+    d = np.linalg.norm(PO, axis=1)
+    sf = scale_factor ** kps["octave"].astype(np.float64)
+    mf_max = (d * sf * rng.uniform(0.85, 1.15, n)).astype(np.float32)          # mfMaxDistance = dist * scale at creation
+    mf_min = (mf_max / np.float32(scale_factor ** (nlevels - 1))).astype(np.float32)
+    nrm = PO / d[:, None] + rng.normal(size=(n, 3)) * 0.25                        # viewCos = PO.Pn / dist, mostly > 0.9
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    dsc = desc.copy()
+    flips = rng.integers(0, 256, size=(n, 6))
+    for k in range(6):
+        dsc[np.arange(n), flips[:, k] // 8] ^= (1 << (flips[:, k] % 8)).astype(np.uint8)
+    pts = dict(cand=np.ones(n, np.uint8), Xw=Xw, normal=nrm, min_dist=np.float32(0.8) * mf_min, max_dist=np.float32(1.2) * mf_max,
+               mf_max_dist=mf_max, desc=dsc, obs=rng.integers(0, 4, n).astype(np.int32))
+    ex = n_extra
+    eX = Ow + (rng.normal(size=(ex, 3)) * np.array([1.5, 1.2, 2.5]) + np.array([0, 0, 1.0])) @ R
+    ed = np.linalg.norm(eX - Ow, axis=1)
+    emf = (ed * rng.uniform(0.3, 3.0, ex)).astype(np.float32)
+    en = rng.normal(size=(ex, 3))
+    en /= np.linalg.norm(en, axis=1)[:, None]
+    extra = dict(cand=(rng.random(ex) > 0.1).astype(np.uint8), Xw=eX, normal=en, min_dist=np.float32(0.8) * emf / np.float32(3.58),
+                 max_dist=np.float32(1.2) * emf, mf_max_dist=emf, desc=rng.integers(0, 256, size=(ex, 32)).astype(np.uint8),
+                 obs=rng.integers(0, 3, ex).astype(np.int32))
+    out = {k: np.concatenate([pts[k], extra[k]]) for k in pts}
+    perm = rng.permutation(n + ex)
+    return {k: np.ascontiguousarray(v[perm]) for k, v in out.items()}

@@ -96,7 +96,8 @@ def test_image_align_modes(sd, oracle, rig):
 
 def test_search_by_projection_bit_exact(sd, oracle, rig):
     trk, B = rig["trk"], rig["B"]
-    for th, check_ori, use_truth in [(8.0, True, True), (16.0, True, False), (8.0, False, True)]:
+    # th = 64: windows of hundreds of pixels overflow the LDS candidate list (per-point slow path of the kernel)
+    for th, check_ori, use_truth in [(8.0, True, True), (16.0, True, False), (8.0, False, True), (64.0, True, True)]:
         T = [s["T_cur"] if use_truth else synth.se3_exp((0.004, 0, 0), (0, 0.1, 0)) @ s["T_cur"] for s in rig["scenes"]]
         trk.set_poses(0, [s["T_ref"] for s in rig["scenes"]], T)
         trk.match(B, th=th, mono=True, check_ori=check_ori)
@@ -304,3 +305,49 @@ def test_pipelined_steps_match_isolated_steps(sd, oracle):
     for x, y in zip(iso, pip):
         assert np.array_equal(x, y)
     assert pip[2].min() > 50
+
+
+def test_local_map_search_bit_exact(sd, oracle, rig):
+    """TrackLocalMap's search (isInFrustum + PredictScale + SearchByProjection(F, vpMapPoints, th)): in-view flags,
+    projections, predicted levels and the assignment vector equal the oracle's, for th = 1 / 3 / 5 (mono, RGB-D,
+    after relocalisation: src/Tracking.cc:931-937), with claimed keypoints, stereo gates and a list overflow."""
+    trk, B = rig["trk"], rig["B"]
+    log_sf = np.log(np.float32(CFG[1]))
+    T = [s["T_cur"] for s in rig["scenes"]]
+    trk.set_poses(0, [s["T_ref"] for s in rig["scenes"]], T)
+    cases = [synth.local_map_case(100 + i, rig["oras"][i]["ck"], rig["oras"][i]["cd"], T[i], n_extra=300 - 100 * (i % 2)) for i in range(B)]
+    # cap the local maps at the tracker's max_points
+    cases = [{k: v[:1000] for k, v in c.items()} for c in cases]
+    claimed = []
+    for i in range(B):
+        c = np.zeros(len(rig["oras"][i]["ck"]), np.uint8)
+        c[i::7] = 1
+        claimed.append(c)
+    ur = np.full((B, 1000), -1, np.float32)
+    for i in range(B):
+        n = len(rig["oras"][i]["ck"])
+        ur[i, :n:3] = rig["oras"][i]["ck"]["x"][::3] - 3.0     # some keypoints carry a right coordinate
+    try:
+        trk.set_camera(*K, 4.0, BOUNDS)
+        trk.set_uright(0, ur)
+        trk.set_local(0, cases, kp_claimed=claimed)
+        for th, nn in [(1.0, 0.8), (3.0, 0.8), (5.0, 0.6), (40.0, 0.9)]:     # th = 40 overflows the LDS candidate list
+            trk.match_local(B, th=th, nnratio=nn)
+            g = trk.get_local(0, B)
+            for i in range(B):
+                o = rig["oras"][i]
+                n = len(o["ck"])
+                r = oracle.search_local_points(o["ck"], o["cd"], o["tab"]["sf"], log_sf, BOUNDS, K, 4.0, T[i], cases[i], th=th, nnratio=nn,
+                                               u_right=ur[i, :n], kp_claimed=claimed[i])
+                M = len(cases[i]["cand"])
+                assert np.array_equal(g["in_view"][i, :M], r["in_view"]), (th, i)
+                assert np.array_equal(g["proj"][i, :M], r["proj"]) and np.array_equal(g["level"][i, :M], r["level"])
+                assert np.array_equal(g["cos"][i, :M], r["cos"])
+                assert g["n"][i] == r["n"], (th, i, g["n"][i], r["n"])
+                assert np.array_equal(g["match"][i, :n], r["match"]), (th, i)
+                assert (g["match"][i, n:] == -1).all()
+                if th == 1.0:
+                    assert r["n"] > 200
+    finally:
+        trk.set_camera(*K, 0.0, BOUNDS)
+        trk.stereo_from_depth(np.zeros((B, 480, 640), np.float32))   # resets every mvuRight to -1
