@@ -282,6 +282,27 @@ def search_local_points(kps_un, desc, sf, log_sf, bounds, K, mbf, T_cw, pts, th=
     return dict(n=n, match=match, in_view=inv.astype(bool), proj=proj, level=lvl, cos=cs)
 
 
+def pose_optimization(kps_un, has_mp, Xw, inv_sigma2, K, T_cw, u_right=None, bf=0.0):
+    """Optimizer::PoseOptimization (g2o Levenberg, Huber, 4 x 10 iterations).  Returns dict(n_inliers, T, outlier[N], info[5])."""
+    L = lib()
+    kps_un = np.ascontiguousarray(kps_un)
+    N = len(kps_un)
+    xy = np.ascontiguousarray(np.stack([kps_un["x"], kps_un["y"]], 1), np.float32)
+    oc = np.ascontiguousarray(kps_un["octave"], np.int32)
+    hm = np.ascontiguousarray(has_mp, np.uint8)
+    X = np.ascontiguousarray(Xw, np.float64)
+    ur = np.full(N, -1, np.float32) if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    isg = np.ascontiguousarray(inv_sigma2, np.float32)
+    Tc = _cm(T_cw)
+    To = np.zeros(16)
+    out = np.zeros(N, np.uint8)
+    info = np.zeros(5, np.int32)
+    L.orc_pose_optimization.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 5 + [C.c_void_p] * 4
+    n = L.orc_pose_optimization(N, _p(hm), _p(xy), _p(oc), _p(ur), _p(isg), _p(X), float(K[0]), float(K[1]), float(K[2]), float(K[3]),
+                                float(bf), _p(Tc), _p(To), _p(out), _p(info))
+    return dict(n_inliers=n, T=_from_cm(To), outlier=out.astype(bool), info=info)
+
+
 def stereo_from_rgbd(kps, kps_un, depth, mbf):
     """Frame::ComputeStereoFromRGBD -> (mvuRight, mvDepth)."""
     L = lib()

@@ -285,3 +285,52 @@ def test_search_local_points_kat(oracle):
     dist = np.linalg.norm(pts["Xw"][iv] - Ow, axis=1).astype(np.float32)
     lvl = np.clip(np.ceil(np.log(pts["mf_max_dist"][iv] / dist) / log_sf), 0, 7).astype(np.int32)
     assert (lvl == r["level"][iv]).mean() > 0.999
+
+
+def _pose_opt_case(seed, n=400, n_out=60, stereo=False):
+    from sdslam_amd import synth
+    from oracle.oracle import KP_DTYPE
+    rng = np.random.default_rng(seed)
+    K = (synth.FX, synth.FY, synth.CX, synth.CY)
+    T_true = synth.se3_exp(rng.normal(size=3) * 0.05, rng.normal(size=3) * 0.3)
+    kps = np.zeros(n, KP_DTYPE)
+    kps["x"], kps["y"] = rng.uniform(20, 620, n), rng.uniform(20, 460, n)
+    kps["octave"] = rng.integers(0, 8, n)
+    z = rng.uniform(1.0, 5.0, n)
+    Xc = np.stack([(kps["x"] - K[2]) / K[0] * z, (kps["y"] - K[3]) / K[1] * z, z], 1).astype(np.float64)
+    Xw = (Xc - T_true[:3, 3]) @ T_true[:3, :3]                      # R^T (Xc - t)
+    sigma = 1.2 ** kps["octave"]
+    kps["x"] += rng.normal(size=n) * 0.4 * sigma
+    kps["y"] += rng.normal(size=n) * 0.4 * sigma
+    bad = rng.choice(n, n_out, replace=False)
+    kps["x"][bad] += rng.uniform(15, 60, n_out) * rng.choice([-1, 1], n_out)
+    has = np.ones(n, np.uint8)
+    has[rng.choice(n, 40, replace=False)] = 0
+    ur = None
+    if stereo:
+        ur = np.where(rng.random(n) < 0.6, kps["x"] - 40.0 / z.astype(np.float32), -1).astype(np.float32)
+    T0 = synth.se3_exp((0.01, -0.02, 0.015), (0.02, -0.01, 0.03)) @ T_true
+    return K, kps, has, Xw, ur, T_true, T0, bad
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_pose_optimization_kat(oracle, stereo):
+    """Optimizer::PoseOptimization restatement: recovers a perturbed pose from noisy projections, flags the planted
+    gross outliers, leaves keypoints without a map point alone, returns nInitial - nBad."""
+    K, kps, has, Xw, ur, T_true, T0, bad = _pose_opt_case(3, stereo=stereo)
+    inv_s2 = (1.0 / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
+    r = oracle.pose_optimization(kps, has, Xw, inv_s2, K, T0, u_right=ur, bf=40.0)
+    assert np.abs(r["T"][:3, 3] - T_true[:3, 3]).max() < 5e-3 and np.abs(r["T"][:3, :3] - T_true[:3, :3]).max() < 2e-3
+    assert np.abs(r["T"][:3, :3] @ r["T"][:3, :3].T - np.eye(3)).max() < 1e-12
+    planted = np.zeros(len(kps), bool)
+    planted[bad] = True
+    planted &= has.astype(bool)
+    assert r["outlier"][planted].all() and not r["outlier"][has == 0].any()
+    assert r["outlier"][~planted & (has != 0)].mean() < 0.12          # chi2 > 5.991 / 7.815: a few percent of true inliers
+    assert r["n_inliers"] == has.sum() - r["outlier"].sum() == r["info"][0] - r["info"][1]
+    assert r["info"][2] == 4 and 4 <= r["info"][3] <= 40 and r["info"][4] >= r["info"][3]
+    # fewer than 3 correspondences: nothing happens
+    h2 = np.zeros_like(has)
+    h2[:2] = 1
+    r2 = oracle.pose_optimization(kps, h2, Xw, inv_s2, K, T0)
+    assert r2["n_inliers"] == 0 and np.array_equal(r2["T"], T0) and r2["info"][2] == 0
