@@ -224,6 +224,20 @@ class ORBmatcher {
   bool mbCheckOrientation;
 };
 
+// Optimizer::PoseOptimization (src/Optimizer.h: static int PoseOptimization(Frame*)), batched.
+class Optimizer {
+ public:
+  // source 0: map points of ORBmatcher::SearchByProjection(batch, ...); 1: of SearchLocalPoints
+  static void PoseOptimization(TrackBatch& batch, int n_frames, int source = 0) { check(sd_track_pose_opt(batch.handle(), n_frames, source)); }
+  // returns nInitialCorrespondences - nBad; Tcw = 16 doubles column-major; mvbOutlier resized to kp_cap
+  static int Result(TrackBatch& batch, int frame, double Tcw[16], std::vector<uint8_t>& mvbOutlier, int kp_cap) {
+    mvbOutlier.resize(kp_cap);
+    int32_t info[8];
+    check(sd_track_get_pose_opt(batch.handle(), frame, 1, Tcw, mvbOutlier.data(), kp_cap, info));
+    return info[5];
+  }
+};
+
 class PnPsolver {
  public:
   PnPsolver() { SetRansacParameters(); }

@@ -178,6 +178,15 @@ int sd_track_match_local(sd_track* h, int n_frames, float th, float nnratio, flo
 int sd_track_get_local(sd_track* h, int frame0, int n_frames, int32_t* local_match, int cap, int32_t* n_matches,
                        uint8_t* in_view, float* proj3, int32_t* level, float* view_cos);
 
+/* Optimizer::PoseOptimization(Frame*) (reference src/Optimizer.cc:221-415: g2o Levenberg, Huber kernel, 4 rounds of
+ * 10 iterations with outlier re-classification), the pose solve the reference runs after SearchByProjection
+ * (src/Tracking.cc:693) and after the local-map search (:729).  Input pose = the frames' current poses; map points =
+ * the matches of sd_track_match (source 0) or sd_track_match_local (source 1); stereo observations where
+ * mvuRight >= 0.  Results: optimised Tcw (16 doubles column-major), mvbOutlier flags, info8 = {nInitialCorrespondences,
+ * nBad, rounds, g2o iterations, LM trials, return value (nInitial - nBad), 0, 0}. */
+int sd_track_pose_opt(sd_track* h, int n_frames, int source);
+int sd_track_get_pose_opt(sd_track* h, int frame0, int n_frames, double* Tcw_cm, uint8_t* outlier, int cap, int32_t* info8);
+
 int sd_track_align(sd_track* h, int n_frames, int mode);
 int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori);
 int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers, int max_iterations,

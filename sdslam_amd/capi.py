@@ -424,6 +424,19 @@ class Tracker:
         _check(self.L.sd_track_get_local(self.h, frame0, n, _p(lm), self.cap, _p(nm), _p(iv), _p(pr), _p(lv), _p(cs)))
         return dict(match=lm, n=nm, in_view=iv.astype(bool), proj=pr, level=lv, cos=cs)
 
+    def pose_opt(self, n_frames, source=0):
+        self.L.sd_track_pose_opt.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _check(self.L.sd_track_pose_opt(self.h, n_frames, int(source)))
+
+    def get_pose_opt(self, frame0, n):
+        T = np.zeros((n, 16))
+        out = np.zeros((n, self.cap), np.uint8)
+        info = np.zeros((n, 8), np.int32)
+        self.L.sd_track_get_pose_opt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _check(self.L.sd_track_get_pose_opt(self.h, frame0, n, _p(T), _p(out), self.cap, _p(info)))
+        return dict(T=[_from_cm(t) for t in T], outlier=out.astype(bool), n_initial=info[:, 0], n_bad=info[:, 1], rounds=info[:, 2],
+                    iterations=info[:, 3], lm_trials=info[:, 4], n_inliers=info[:, 5])
+
     def align(self, n_frames, mode=0):
         _check(self.L.sd_track_align(self.h, n_frames, mode))
 

@@ -31,6 +31,7 @@ struct sd_track {
   float* d_sf = nullptr;
   float* d_inv_sf = nullptr;
   float* d_sigma2 = nullptr;
+  float* d_inv_sigma2 = nullptr;
   float* d_scale_thr = nullptr;   // MapPoint::PredictScale breakpoints (see k_match_local)
   std::vector<void*> allocs;
   // The tracking kernels (align, match, PnP: latency-bound, few waves) run on their own stream, so
@@ -124,6 +125,10 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.lm_cos, B * M));
   A(dalloc(h, &tb.lm_match, B * K));
   A(dalloc(h, &tb.lm_nmatch, B));
+  A(dalloc(h, &tb.po_T, B * 16));
+  A(dalloc(h, &tb.po_outlier, B * K));
+  A(dalloc(h, &tb.po_info, B * 8));
+  A(dalloc(h, &h->d_inv_sigma2, (size_t)cur->nlevels));
   A(dalloc(h, &h->d_scale_thr, (size_t)SD_MAX_LEVELS));
   A(dalloc(h, &h->d_sf, (size_t)cur->nlevels));
   A(dalloc(h, &h->d_inv_sf, (size_t)cur->nlevels));
@@ -138,6 +143,7 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
     hipError_t e = hipMemcpy(h->d_sf, cur->hp.sf.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_inv_sf, cur->hp.inv_sf.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_sigma2, cur->hp.sigma2.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_inv_sigma2, cur->hp.inv_sigma2.data(), cur->nlevels * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
       // MapPoint::PredictScale (src/MapPoint.cc:371-385): nScale = ceil(log(ratio) / mfLogScaleFactor), float overloads,
       // mfLogScaleFactor = log(mfScaleFactor) (src/Frame.cc:80).  thr[n] = smallest float ratio that reaches level n,
@@ -368,6 +374,33 @@ int sd_track_get_local(sd_track* h, int frame0, int n_frames, int32_t* local_mat
   if (proj3) SD_HIP_CHECK(hipMemcpyAsync(proj3, tb.lm_proj + o * M * 3, n * M * 12, hipMemcpyDeviceToHost, s));
   if (level) SD_HIP_CHECK(hipMemcpyAsync(level, tb.lm_level + o * M, n * M * 4, hipMemcpyDeviceToHost, s));
   if (view_cos) SD_HIP_CHECK(hipMemcpyAsync(view_cos, tb.lm_cos + o * M, n * M * 4, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
+}
+
+// Optimizer::PoseOptimization(&CurrentFrame) at the frames' current poses (tb.Tcur: sd_track_set_poses / ImageAlign result).
+// source 0: mvpMapPoints = the frame-to-frame matches (sd_track_match); 1: the local-map matches (sd_track_match_local).
+int sd_track_pose_opt(sd_track* h, int n_frames, int source) {
+  int rc = check_ready(h, n_frames);
+  if (rc != SD_OK) return rc;
+  SD_REQUIRE(source == 0 || source == 1, SD_ERR_INVALID_ARG, "source must be 0 (frame matches) or 1 (local-map matches)");
+  hipStream_t s = h->pnp_stream;
+  rc = wait_inputs(h, false);
+  if (rc != SD_OK) return rc;
+  rc = launch_pose_opt(h->cur, h->tb, h->cam, h->d_inv_sigma2, source, n_frames, s);
+  if (rc == SD_OK) rc = mark_reads(h, false);
+  return rc;
+}
+
+int sd_track_get_pose_opt(sd_track* h, int frame0, int n_frames, double* Tcw_cm, uint8_t* outlier, int cap, int32_t* info8) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(!outlier || cap >= h->kp_cap, SD_ERR_CAPACITY, "cap smaller than the keypoint capacity");
+  hipStream_t s = h->cur->stream;
+  if (Tcw_cm) SD_HIP_CHECK(hipMemcpyAsync(Tcw_cm, h->tb.po_T + (size_t)frame0 * 16, (size_t)n_frames * 128, hipMemcpyDeviceToHost, s));
+  if (outlier)
+    SD_HIP_CHECK(hipMemcpy2DAsync(outlier, cap, h->tb.po_outlier + (size_t)frame0 * h->kp_cap, h->kp_cap, h->kp_cap, n_frames,
+                                  hipMemcpyDeviceToHost, s));
+  if (info8) SD_HIP_CHECK(hipMemcpyAsync(info8, h->tb.po_info + (size_t)frame0 * 8, (size_t)n_frames * 32, hipMemcpyDeviceToHost, s));
   SD_HIP_CHECK(hipStreamSynchronize(s));
   return SD_OK;
 }

@@ -59,6 +59,10 @@ struct TrackBuffers {
   float* lm_cos;         // [B][M]   mTrackViewCos
   int32_t* lm_match;     // [B][kp_cap] index into the local-map arrays or -1
   int32_t* lm_nmatch;    // [B]
+  // Optimizer::PoseOptimization outputs
+  double* po_T;          // [B][16] optimised Tcw, column-major
+  uint8_t* po_outlier;   // [B][kp_cap] mvbOutlier
+  int32_t* po_info;      // [B][8]: nInitialCorrespondences, nBad, rounds, g2o iterations, LM trials, nInitial - nBad
 };
 
 struct TrackCam {
@@ -80,6 +84,8 @@ int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, c
                  const float* d_sf, int n_frames, int mode, hipStream_t s);
 int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, int n_frames, float th,
                  int mono, int check_ori, hipStream_t s);
+int launch_pose_opt(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sigma2, int source, int n_frames,
+                    hipStream_t s);
 int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, const float* d_scale_thr,
                        int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s);
 int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_depth, int w, int h,

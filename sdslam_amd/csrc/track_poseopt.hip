@@ -1,0 +1,493 @@
+// Optimizer::PoseOptimization on MI355X: the motion-only bundle adjustment the reference runs after every
+// SearchByProjection (src/Tracking.cc:693, 729), one wavefront per frame.
+//
+// Replaces (reference file:line)
+//   Optimizer::PoseOptimization                                   src/Optimizer.cc:221-415
+//   g2o OptimizationAlgorithmLevenberg::solve & friends           src/extra/g2o/core/optimization_algorithm_levenberg.cpp:60-187
+//   g2o BlockSolver::buildSystem / BaseUnaryEdge::constructQuadraticForm / RobustKernelHuber
+//                                                                 src/extra/g2o/core/block_solver.hpp:502-604, base_unary_edge.hpp:43-72,
+//                                                                 robust_kernel_impl.cpp:78-91
+//   g2o LinearSolverDense (Eigen::LDLT, isPositive)               src/extra/g2o/solvers/linear_solver_dense.h:65-116
+//   EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose   src/extra/g2o/types/types_six_dof_expmap.{h,cpp}
+//   SE3Quat::exp / operator* / map, VertexSE3Expmap::oplusImpl    src/extra/g2o/types/se3quat.h, types_six_dof_expmap.h:73-76
+//
+// Shape: the graph has ONE 6-DoF vertex and up to ~1000 unary edges, so an LM step is two reductions over the
+// edges (robust chi2; 21 + 6 entries of H and b) around a 6x6 solve.  Lane l owns keypoints l, l + 64, ...: it
+// re-derives each edge from the resident arrays (undistorted keypoint, level sigma, matched map point) instead of
+// storing per-edge state, accumulates in fp64 and the wave combines with xor-butterflies (every lane ends with the
+// same bits).  Lane 0 factorises H + lambda I in LDS (pivoted LDLT, Eigen semantics incl. isPositive); all lanes
+// replay the scalar LM logic in lock step.  g2o adds edges in keypoint order and sums them sequentially; the
+// butterfly order differs, so this stage is compared at a tolerance (pose 1e-5, identical outlier flags), like
+// ImageAlign's H.  Quirks kept: every round restarts from the frame's initial pose; edges are classified with the
+// errors of the last computeActiveErrors (after a rejected trial: the rejected estimate's) -- kept as "the estimate
+// at which errors were last computed" rather than per-edge error storage; Huber removed after the third round.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "orb_internal.h"
+#include "track_internal.h"
+
+namespace sd {
+
+struct Se3q {
+  double q[4];   // x, y, z, w
+  double t[3];
+};
+
+__device__ __forceinline__ void q_normalize(double* q) {
+  if (q[3] < 0)
+    for (int i = 0; i < 4; i++) q[i] *= -1;
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; i++) q[i] /= n;
+}
+
+__device__ __forceinline__ void q_from_R(const double m[3][3], double* q) {   // Eigen QuaternionBase::operator=(MatrixBase)
+  double t = m[0][0] + m[1][1] + m[2][2];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[2][1] - m[1][2]) * t;
+    q[1] = (m[0][2] - m[2][0]) * t;
+    q[2] = (m[1][0] - m[0][1]) * t;
+  } else {
+    // i = index of the largest diagonal entry, written without run-time indexing
+    const bool i1 = m[1][1] > m[0][0];
+    const bool i2 = m[2][2] > (i1 ? m[1][1] : m[0][0]);
+    if (i2) {          // i = 2, j = 0, k = 1
+      t = sqrt(m[2][2] - m[0][0] - m[1][1] + 1.0);
+      q[2] = 0.5 * t;
+      t = 0.5 / t;
+      q[3] = (m[1][0] - m[0][1]) * t;
+      q[0] = (m[0][2] + m[2][0]) * t;
+      q[1] = (m[1][2] + m[2][1]) * t;
+    } else if (i1) {   // i = 1, j = 2, k = 0
+      t = sqrt(m[1][1] - m[2][2] - m[0][0] + 1.0);
+      q[1] = 0.5 * t;
+      t = 0.5 / t;
+      q[3] = (m[0][2] - m[2][0]) * t;
+      q[2] = (m[2][1] + m[1][2]) * t;
+      q[0] = (m[0][1] + m[1][0]) * t;
+    } else {           // i = 0, j = 1, k = 2
+      t = sqrt(m[0][0] - m[1][1] - m[2][2] + 1.0);
+      q[0] = 0.5 * t;
+      t = 0.5 / t;
+      q[3] = (m[2][1] - m[1][2]) * t;
+      q[1] = (m[1][0] + m[0][1]) * t;
+      q[2] = (m[2][0] + m[0][2]) * t;
+    }
+  }
+}
+
+__device__ __forceinline__ void q_mul(const double* a, const double* b, double* r) {
+  const double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  const double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  const double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  const double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z; r[3] = w;
+}
+
+__device__ __forceinline__ void q_rotate(const double* q, const double* v, double* r) {
+  double uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+  for (int i = 0; i < 3; i++) uv[i] += uv[i];
+  const double c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+  for (int i = 0; i < 3; i++) r[i] = v[i] + q[3] * uv[i] + c[i];
+}
+
+__device__ __forceinline__ Se3q se3_from_Rt(const double R[3][3], const double* t) {
+  Se3q s;
+  q_from_R(R, s.q);
+  for (int i = 0; i < 3; i++) s.t[i] = t[i];
+  q_normalize(s.q);
+  return s;
+}
+
+__device__ __forceinline__ Se3q se3q_mul(const Se3q& a, const Se3q& b) {
+  Se3q r = a;
+  double rt[3];
+  q_rotate(a.q, b.t, rt);
+  for (int i = 0; i < 3; i++) r.t[i] += rt[i];
+  q_mul(a.q, b.q, r.q);
+  q_normalize(r.q);
+  return r;
+}
+
+__device__ __noinline__ Se3q se3q_exp(const double* update) {   // SE3Quat::exp
+  const double omega[3] = {update[0], update[1], update[2]}, upsilon[3] = {update[3], update[4], update[5]};
+  const double theta = sqrt(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]);
+  const double Om[3][3] = {{0, -omega[2], omega[1]}, {omega[2], 0, -omega[0]}, {-omega[1], omega[0], 0}};
+  double Om2[3][3], R[3][3], V[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Om2[i][j] = Om[i][0] * Om[0][j] + Om[i][1] * Om[1][j] + Om[i][2] * Om[2][j];
+  if (theta < 0.00001) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) V[i][j] = R[i][j] = ((i == j ? 1.0 : 0.0) + Om[i][j]) + Om2[i][j];
+  } else {
+    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3.0);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        R[i][j] = ((i == j ? 1.0 : 0.0) + a * Om[i][j]) + b * Om2[i][j];
+        V[i][j] = ((i == j ? 1.0 : 0.0) + b * Om[i][j]) + c * Om2[i][j];
+      }
+  }
+  double t[3];
+  for (int i = 0; i < 3; i++) t[i] = V[i][0] * upsilon[0] + V[i][1] * upsilon[1] + V[i][2] * upsilon[2];
+  return se3_from_Rt(R, t);
+}
+
+// Eigen 3.3 LDLT (pivoting on the largest |diagonal|, sign tracking) + solve, 6x6 in LDS, one lane.
+// Returns 1 if isPositive().  Same elimination as ldlt_solve6 in track_align.hip.
+#define PA_(r, c) A[(r) * 6 + (c)]
+__device__ __noinline__ int ldlt6_solve_sign(double* A, const double* b, double* x) {
+  const int n = 6;
+  int tr[6];
+  double temp[6];
+  int sign = 0;   // 0 zero, 1 positive semidefinite, -1 negative semidefinite, 2 indefinite
+  bool found_zero_pivot = false;
+  for (int k = 0; k < n; ++k) {
+    int big = k;
+    double best = fabs(PA_(k, k));
+    for (int i = k + 1; i < n; i++)
+      if (fabs(PA_(i, i)) > best) { best = fabs(PA_(i, i)); big = i; }
+    tr[k] = big;
+    if (k != big) {
+      const int s = n - big - 1;
+      for (int j = 0; j < k; j++) { double t = PA_(k, j); PA_(k, j) = PA_(big, j); PA_(big, j) = t; }
+      for (int i = 0; i < s; i++) { double t = PA_(big + 1 + i, k); PA_(big + 1 + i, k) = PA_(big + 1 + i, big); PA_(big + 1 + i, big) = t; }
+      { double t = PA_(k, k); PA_(k, k) = PA_(big, big); PA_(big, big) = t; }
+      for (int i = k + 1; i < big; ++i) { double t = PA_(i, k); PA_(i, k) = PA_(big, i); PA_(big, i) = t; }
+    }
+    const int rs = n - k - 1;
+    if (k > 0) {
+      for (int j = 0; j < k; j++) temp[j] = PA_(j, j) * PA_(k, j);
+      double s = 0;
+      for (int j = 0; j < k; j++) s += PA_(k, j) * temp[j];
+      PA_(k, k) -= s;
+      for (int i = 0; i < rs; i++) {
+        double t = 0;
+        for (int j = 0; j < k; j++) t += PA_(k + 1 + i, j) * temp[j];
+        PA_(k + 1 + i, k) -= t;
+      }
+    }
+    const double akk = PA_(k, k);
+    const bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) {
+      sign = 0;
+      for (int j = 0; j < n; j++) tr[j] = j;
+      break;
+    }
+    if (valid) {
+      for (int i = 0; i < rs; i++) PA_(k + 1 + i, k) /= akk;
+    } else {
+      found_zero_pivot = true;
+    }
+    if (sign == 1) { if (akk < 0) sign = 2; }
+    else if (sign == -1) { if (akk > 0) sign = 2; }
+    else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = -1; }
+    if (found_zero_pivot && valid) sign = 2;
+  }
+  if (!(sign == 1 || sign == 0)) return 0;
+  double y[6];
+  for (int i = 0; i < n; i++) y[i] = b[i];
+  for (int k = 0; k < n; k++) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++) y[i] -= PA_(i, j) * y[j];
+  for (int i = 0; i < n; i++) {
+    if (fabs(PA_(i, i)) > DBL_MIN) y[i] /= PA_(i, i);
+    else y[i] = 0;
+  }
+  for (int i = n - 1; i >= 0; i--)
+    for (int j = i + 1; j < n; j++) y[i] -= PA_(j, i) * y[j];
+  for (int k = n - 1; k >= 0; k--) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+  for (int i = 0; i < n; i++) x[i] = y[i];
+  return 1;
+}
+
+struct PoCam { double fx, fy, cx, cy, bf; };
+
+// error of one edge at estimate T; returns chi2 (= invSigma2 * |e|^2); e[] filled
+__device__ __forceinline__ double po_error(const Se3q& T, const double* Xw, double ox, double oy, double our, bool stereo, double info,
+                                           const PoCam& cam, double* e, double* p) {
+  double r[3];
+  q_rotate(T.q, Xw, r);
+  for (int i = 0; i < 3; i++) p[i] = r[i] + T.t[i];
+  if (!stereo) {
+    const double px = p[0] / p[2], py = p[1] / p[2];
+    e[0] = ox - (px * cam.fx + cam.cx);
+    e[1] = oy - (py * cam.fy + cam.cy);
+    e[2] = 0;
+    return e[0] * (info * e[0]) + e[1] * (info * e[1]);
+  }
+  const float invz = (float)(1.0 / p[2]);   // const float invz = 1.0f / trans_xyz[2]
+  const double r0 = p[0] * invz * cam.fx + cam.cx, r1 = p[1] * invz * cam.fy + cam.cy, r2 = r0 - cam.bf * invz;
+  e[0] = ox - r0;
+  e[1] = oy - r1;
+  e[2] = our - r2;
+  return (e[0] * (info * e[0]) + e[1] * (info * e[1])) + e[2] * (info * e[2]);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// source 0: map points of the frame-to-frame match (tb.cur_match -> tb.Xw); 1: of the local-map search (tb.lm_match -> tb.lm_Xw)
+__global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all, TrackBuffers tb,
+                                                TrackCam tcam, const float* __restrict__ inv_sigma2, int source, int n_frames) {
+  __shared__ double s_A[36], s_b[6], s_x[8];
+  __shared__ int s_ok;
+  const int lane = threadIdx.x;
+  for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
+    __syncthreads();
+    const int cap = tb.kp_cap, M = tb.max_points;
+    const sd_keypoint* kps = kps_all + (size_t)f * cap;
+    const int nkp = min(nkp_all[f], cap);
+    const int32_t* match = (source == 0 ? tb.cur_match : tb.lm_match) + (size_t)f * cap;
+    const double* Xw_all = (source == 0 ? tb.Xw : tb.lm_Xw) + (size_t)f * M * 3;
+    const float* uright = tb.uright + (size_t)f * cap;
+    uint8_t* outl = tb.po_outlier + (size_t)f * cap;
+    double* T_out = tb.po_T + (size_t)f * 16;
+    int32_t* info = tb.po_info + (size_t)f * 8;
+    const double* T_in = tb.Tcur + (size_t)f * 16;
+    const PoCam cam = {(double)tcam.ffx, (double)tcam.ffy, (double)tcam.fcx, (double)tcam.fcy, (double)tcam.bf};
+    const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);   // const float delta = sqrt(..)
+    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+
+    int nInitial = 0;
+    for (int i0 = 0; i0 < nkp; i0 += 64) {
+      const int i = i0 + lane;
+      const bool has = i < nkp && match[i] >= 0;
+      nInitial += __popcll(__ballot(has));
+    }
+    for (int i = lane; i < cap; i += 64) outl[i] = 0;
+    if (lane < 16) T_out[lane] = T_in[lane];
+    if (lane == 0) {
+      for (int k = 0; k < 8; k++) info[k] = 0;
+      info[0] = nInitial;
+    }
+    if (nInitial < 3) continue;
+    double R0[3][3], t0[3];
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) R0[r][c] = T_in[c * 4 + r];
+      t0[r] = T_in[12 + r];
+    }
+    Se3q est = se3_from_Rt(R0, t0), est_err = est;
+    int nBad = 0, its_total = 0, trials_total = 0, rounds = 0;
+    bool robust = true;
+    for (int round = 0; round < 4; round++) {
+      est = se3_from_Rt(R0, t0);   // vSE3->setEstimate(Converter::toSE3Quat(pFrame->GetPose()))
+      // ---------------- optimizer.optimize(10)
+      int n_active = 0;
+      for (int i0 = 0; i0 < nkp; i0 += 64) {
+        const int i = i0 + lane;
+        n_active += __popcll(__ballot(i < nkp && match[i] >= 0 && !outl[i]));
+      }
+      double lambda = -1., ni = 2.;
+      int nBadLM = 0;
+      for (int it = 0; it < 10 && n_active > 0; it++) {
+        // computeActiveErrors + activeRobustChi2 + buildSystem at `est`
+        double H[21], b[6], chi = 0;
+#pragma unroll
+        for (int k = 0; k < 21; k++) H[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) b[k] = 0;
+        for (int i = lane; i < nkp; i += 64) {
+          const int m = match[i];
+          if (m < 0 || outl[i]) continue;
+          const sd_keypoint kp = kps[i];
+          const float ur = uright[i];
+          const bool stereo = !(ur < 0);
+          const double infoe = (double)inv_sigma2[kp.octave];
+          const double Xw[3] = {Xw_all[(size_t)m * 3], Xw_all[(size_t)m * 3 + 1], Xw_all[(size_t)m * 3 + 2]};
+          double e[3], p[3];
+          const double c2 = po_error(est, Xw, kp.x, kp.y, ur, stereo, infoe, cam, e, p);
+          double rho1 = 1.0;
+          if (robust) {
+            const double delta = stereo ? deltaStereo : deltaMono, dsqr = delta * delta;
+            if (c2 <= dsqr) {
+              chi += c2;
+            } else {
+              const double sqrte = sqrt(c2);
+              chi += 2 * sqrte * delta - dsqr;
+              rho1 = delta / sqrte;
+            }
+          } else {
+            chi += c2;
+          }
+          const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
+          double J[3][6];
+          J[0][0] = x * y * invz_2 * cam.fx;
+          J[0][1] = -(1 + (x * x * invz_2)) * cam.fx;
+          J[0][2] = y * invz * cam.fx;
+          J[0][3] = -invz * cam.fx;
+          J[0][4] = 0;
+          J[0][5] = x * invz_2 * cam.fx;
+          J[1][0] = (1 + y * y * invz_2) * cam.fy;
+          J[1][1] = -x * y * invz_2 * cam.fy;
+          J[1][2] = -x * invz * cam.fy;
+          J[1][3] = 0;
+          J[1][4] = -invz * cam.fy;
+          J[1][5] = y * invz_2 * cam.fy;
+          J[2][0] = stereo ? J[0][0] - cam.bf * y * invz_2 : 0.0;
+          J[2][1] = stereo ? J[0][1] + cam.bf * x * invz_2 : 0.0;
+          J[2][2] = stereo ? J[0][2] : 0.0;
+          J[2][3] = stereo ? J[0][3] : 0.0;
+          J[2][4] = 0;
+          J[2][5] = stereo ? J[0][5] - cam.bf * invz_2 : 0.0;
+          const double wi = rho1 * infoe;
+          int q = 0;
+#pragma unroll
+          for (int a = 0; a < 6; a++) {
+            b[a] -= rho1 * ((J[0][a] * (infoe * e[0]) + J[1][a] * (infoe * e[1])) + J[2][a] * (infoe * e[2]));
+#pragma unroll
+            for (int c = a; c < 6; c++) H[q++] += (J[0][a] * (wi * J[0][c]) + J[1][a] * (wi * J[1][c])) + J[2][a] * (wi * J[2][c]);
+          }
+        }
+        est_err = est;
+#pragma unroll
+        for (int k = 0; k < 21; k++) H[k] = wave_sum(H[k]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) b[k] = wave_sum(b[k]);
+        double currentChi = wave_sum(chi), tempChi = currentChi;
+        const double iniChi = currentChi;
+        if (it == 0) {
+          double maxDiagonal = 0.;
+          int q = 0;
+          for (int a = 0; a < 6; a++) {
+            maxDiagonal = fmax(fabs(H[q]), maxDiagonal);
+            q += 6 - a;
+          }
+          lambda = 1e-5 * maxDiagonal;
+          ni = 2;
+          nBadLM = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+          const Se3q backup = est;
+          __syncthreads();
+          if (lane == 0) {
+            int q = 0;
+            for (int a = 0; a < 6; a++)
+              for (int c = a; c < 6; c++) {
+                s_A[a * 6 + c] = H[q];
+                s_A[c * 6 + a] = H[q];
+                q++;
+              }
+            for (int a = 0; a < 6; a++) {
+              s_A[a * 6 + a] += lambda;
+              s_b[a] = b[a];
+            }
+            s_ok = ldlt6_solve_sign(s_A, s_b, s_x);   // on failure s_x keeps the previous solution, like _solver->x()
+          }
+          __syncthreads();
+          const bool ok2 = s_ok != 0;
+          double x[6];
+          for (int k = 0; k < 6; k++) x[k] = s_x[k];
+          est = se3q_mul(se3q_exp(x), est);
+          // computeActiveErrors + activeRobustChi2 at the trial estimate
+          double c = 0;
+          for (int i = lane; i < nkp; i += 64) {
+            const int m = match[i];
+            if (m < 0 || outl[i]) continue;
+            const sd_keypoint kp = kps[i];
+            const float ur = uright[i];
+            const bool stereo = !(ur < 0);
+            const double infoe = (double)inv_sigma2[kp.octave];
+            const double Xw[3] = {Xw_all[(size_t)m * 3], Xw_all[(size_t)m * 3 + 1], Xw_all[(size_t)m * 3 + 2]};
+            double e[3], p[3];
+            const double c2 = po_error(est, Xw, kp.x, kp.y, ur, stereo, infoe, cam, e, p);
+            if (robust) {
+              const double delta = stereo ? deltaStereo : deltaMono, dsqr = delta * delta;
+              c += (c2 <= dsqr) ? c2 : (2 * sqrt(c2) * delta - dsqr);
+            } else {
+              c += c2;
+            }
+          }
+          est_err = est;
+          tempChi = wave_sum(c);
+          if (!ok2) tempChi = DBL_MAX;
+          rho = (currentChi - tempChi);
+          double scale = 0.;
+          for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+          scale += 1e-3;
+          rho /= scale;
+          if (rho > 0 && isfinite(tempChi)) {
+            double alpha = 1. - pow((2 * rho - 1), 3.0);
+            alpha = fmin(alpha, 2. / 3.);
+            const double scaleFactor = fmax(1. / 3., alpha);
+            lambda *= scaleFactor;
+            ni = 2;
+            currentChi = tempChi;
+          } else {
+            lambda *= ni;
+            ni *= 2;
+            est = backup;
+          }
+          qmax++;
+          trials_total++;
+        } while (rho < 0 && qmax < 10);
+        its_total++;
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++;
+        else nBadLM = 0;
+        if (nBadLM >= 3) break;
+      }
+      rounds++;
+      // ---------------- classify (src/Optimizer.cc:353-398)
+      int bad = 0;
+      for (int i0 = 0; i0 < nkp; i0 += 64) {
+        const int i = i0 + lane;
+        bool isbad = false;
+        if (i < nkp && match[i] >= 0) {
+          const int m = match[i];
+          const sd_keypoint kp = kps[i];
+          const float ur = uright[i];
+          const bool stereo = !(ur < 0);
+          const double infoe = (double)inv_sigma2[kp.octave];
+          const double Xw[3] = {Xw_all[(size_t)m * 3], Xw_all[(size_t)m * 3 + 1], Xw_all[(size_t)m * 3 + 2]};
+          double e[3], p[3];
+          // outliers: e->computeError() at the current estimate; the others keep the errors of the last computeActiveErrors
+          const float chi2 = (float)po_error(outl[i] ? est : est_err, Xw, kp.x, kp.y, ur, stereo, infoe, cam, e, p);
+          isbad = chi2 > (stereo ? chi2Stereo : chi2Mono);
+          outl[i] = isbad ? 1 : 0;
+        }
+        bad += __popcll(__ballot(isbad));
+      }
+      nBad = bad;
+      if (round == 2) robust = false;
+      if (nInitial < 10) break;   // optimizer.edges().size() < 10
+    }
+    // ---------------- result
+    if (lane == 0) {
+      const double* q = est.q;
+      const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+      const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+      const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+      const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+      const double Ro[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+      for (int i = 0; i < 16; i++) T_out[i] = (i % 5 == 0) ? 1.0 : 0.0;
+      for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T_out[c * 4 + r] = Ro[r][c];
+        T_out[12 + r] = est.t[r];
+      }
+      info[1] = nBad;
+      info[2] = rounds;
+      info[3] = its_total;
+      info[4] = trials_total;
+      info[5] = nInitial - nBad;
+    }
+  }
+}
+
+int launch_pose_opt(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sigma2, int source, int n_frames,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(64), 0, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam,
+                     d_inv_sigma2, source, n_frames);
+  SD_HIP_CHECK(hipGetLastError());
+  return SD_OK;
+}
+
+}  // namespace sd

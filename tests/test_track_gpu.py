@@ -351,3 +351,75 @@ def test_local_map_search_bit_exact(sd, oracle, rig):
     finally:
         trk.set_camera(*K, 0.0, BOUNDS)
         trk.stereo_from_depth(np.zeros((B, 480, 640), np.float32))   # resets every mvuRight to -1
+
+
+def test_pose_optimization_matches_oracle(sd, oracle, rig):
+    """Optimizer::PoseOptimization on the frame-to-frame matches (source 0) and on the local-map matches (source 1),
+    mono and with stereo observations: pose within 1e-5 of the oracle's g2o restatement, identical outlier flags
+    and return values."""
+    trk, B = rig["trk"], rig["B"]
+    T = [synth.se3_exp((0.004, -0.003, 0.002), (0.01, 0.008, -0.012)) @ s["T_cur"] for s in rig["scenes"]]
+    trk.set_last(0, [o["last"] for o in rig["oras"]])
+    trk.set_poses(0, [s["T_ref"] for s in rig["scenes"]], [s["T_cur"] for s in rig["scenes"]])
+    trk.match(B, th=8.0, mono=True, check_ori=True)
+    cm, nm = trk.get_matches(0, B)
+    trk.set_poses(0, [s["T_ref"] for s in rig["scenes"]], T)          # start PoseOptimization from a perturbed pose
+    inv_s2 = rig["oras"][0]["tab"]["inv_sigma2"]
+    ur = np.full((B, 1000), -1, np.float32)
+    for stereo in (False, True):
+        try:
+            if stereo:
+                for i in range(B):
+                    o = rig["oras"][i]
+                    n = len(o["ck"])
+                    Xw = o["last"]["Xw"][np.maximum(cm[i, :n], 0)]
+                    zc = (Xw @ rig["scenes"][i]["T_cur"][:3, :3].T + rig["scenes"][i]["T_cur"][:3, 3])[:, 2]
+                    ur[i, :n] = np.where(np.arange(n) % 3 == 0, o["ck"]["x"] - 40.0 / zc, -1).astype(np.float32)
+                trk.set_camera(*K, 40.0, BOUNDS)
+                trk.set_uright(0, ur)
+            trk.pose_opt(B, source=0)
+            g = trk.get_pose_opt(0, B)
+            for i in range(B):
+                o = rig["oras"][i]
+                n = len(o["ck"])
+                has = cm[i, :n] >= 0
+                r = oracle.pose_optimization(o["ck"], has, o["last"]["Xw"][np.maximum(cm[i, :n], 0)], inv_s2, K, T[i],
+                                             u_right=ur[i, :n] if stereo else None, bf=40.0 if stereo else 0.0)
+                assert np.abs(g["T"][i] - r["T"]).max() <= POSE_TOL, (stereo, i, np.abs(g["T"][i] - r["T"]).max())
+                assert np.array_equal(g["outlier"][i, :n], r["outlier"]) and not g["outlier"][i, n:].any()
+                assert g["n_inliers"][i] == r["n_inliers"] and g["n_initial"][i] == r["info"][0] and g["n_bad"][i] == r["info"][1]
+                # (g2o iteration / LM trial counts are not compared: once converged, the sign of rho is summation-order noise)
+                assert g["rounds"][i] == 4 and 4 <= g["iterations"][i] <= 40 and g["lm_trials"][i] >= g["iterations"][i]
+                assert np.abs(g["T"][i][:3, 3] - rig["scenes"][i]["T_cur"][:3, 3]).max() < 5e-3     # and it converges to the truth
+        finally:
+            trk.set_camera(*K, 0.0, BOUNDS)
+            trk.stereo_from_depth(np.zeros((B, 480, 640), np.float32))
+    # source 1: local-map matches
+    Tc = [s["T_cur"] for s in rig["scenes"]]
+    trk.set_poses(0, [s["T_ref"] for s in rig["scenes"]], Tc)
+    cases = [{k: v[:1000] for k, v in synth.local_map_case(200 + i, rig["oras"][i]["ck"], rig["oras"][i]["cd"], Tc[i]).items()} for i in range(B)]
+    trk.set_local(0, cases)
+    trk.match_local(B, th=1.0, nnratio=0.8)
+    lm = trk.get_local(0, B)["match"]
+    trk.set_poses(0, [s["T_ref"] for s in rig["scenes"]], T)
+    trk.pose_opt(B, source=1)
+    g = trk.get_pose_opt(0, B)
+    for i in range(B):
+        o = rig["oras"][i]
+        n = len(o["ck"])
+        has = lm[i, :n] >= 0
+        r = oracle.pose_optimization(o["ck"], has, cases[i]["Xw"][np.maximum(lm[i, :n], 0)], inv_s2, K, T[i])
+        assert np.abs(g["T"][i] - r["T"]).max() <= POSE_TOL
+        assert np.array_equal(g["outlier"][i, :n], r["outlier"]) and g["n_inliers"][i] == r["n_inliers"]
+    # degenerate: fewer than 3 correspondences -> pose untouched, return value 0
+    empty = [dict(o["last"]) for o in rig["oras"]]
+    for c in empty:
+        c["valid"] = np.zeros_like(c["valid"])
+    trk.set_last(0, empty)
+    trk.set_poses(0, [s["T_ref"] for s in rig["scenes"]], T)
+    trk.match(B, th=8.0, mono=True, check_ori=True)
+    trk.pose_opt(B, source=0)
+    g = trk.get_pose_opt(0, B)
+    for i in range(B):
+        assert g["n_inliers"][i] == 0 and g["rounds"][i] == 0 and np.abs(g["T"][i] - T[i]).max() == 0
+    trk.set_last(0, [o["last"] for o in rig["oras"]])
