@@ -50,7 +50,7 @@ def make_cases(n_unique, seed0):
     return scenes
 
 
-def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0):
+def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0, pose_solver="pnp"):
     """The oracle's full tracking step (-O3 -march=native build) on this host: 1 thread."""
     from oracle import oracle as O
     from sdslam_amd import synth
@@ -80,9 +80,12 @@ def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0):
         valid = (cm >= 0).astype(np.uint8)
         Xw = np.zeros((len(ck), 3))
         Xw[valid != 0] = last["Xw"][cm[valid != 0]]
-        p = O.PnPOracle(valid, np.stack([ck["x"], ck["y"]], 1), ck["octave"], tab["sigma2"], Xw, K)
-        p.set_ransac(PNP["probability"], PNP["min_inliers"], PNP["max_iterations"], 4, PNP["epsilon"], PNP["th2"])
-        p.iterate(PNP["max_iterations"], rs)
+        if pose_solver == "pnp":
+            p = O.PnPOracle(valid, np.stack([ck["x"], ck["y"]], 1), ck["octave"], tab["sigma2"], Xw, K)
+            p.set_ransac(PNP["probability"], PNP["min_inliers"], PNP["max_iterations"], 4, PNP["epsilon"], PNP["th2"])
+            p.iterate(PNP["max_iterations"], rs)
+        else:
+            O.pose_optimization(ck, valid, Xw, tab["inv_sigma2"], K, r["T"])
         te = time.perf_counter()
         t_stage += [tb - ta, tc - tb2, td - tc, te - td]
         n += 1
@@ -90,10 +93,11 @@ def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0):
             break
     dt = t_stage.sum()      # excludes the Python-side pyramid copies between the C calls
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} VGA frame pairs, full step (ORB extract + ImageAlign + SearchByProjection + PnP RANSAC), "
+            "sample": f"{n} VGA frame pairs, full step (ORB extract + ImageAlign + SearchByProjection + "
+                      f"{'PnP RANSAC' if pose_solver == 'pnp' else 'PoseOptimization'}), "
                       f"1 thread of {os.cpu_count()} host cpus",
             "ms_per_frame": {"orb_extract": t_stage[0] / n * 1e3, "image_align": t_stage[1] / n * 1e3,
-                             "search_by_projection": t_stage[2] / n * 1e3, "pnp_ransac": t_stage[3] / n * 1e3}}
+                             "search_by_projection": t_stage[2] / n * 1e3, "pose_solve": t_stage[3] / n * 1e3}}
 
 
 STAGE_KERNELS = {"pyramid": ["k_pyr_resize", "k_pyr_edges", "k_pyr_rows", "k_pyr_level"], "fast_nms": ["k_fast_cells"],
@@ -141,6 +145,9 @@ def main():
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic scenes (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--orb-only", action="store_true", help="time ORB extraction alone (configs[1] without tracking)")
+    ap.add_argument("--pose-solver", choices=["pnp", "poseopt"], default="pnp",
+                    help="pnp: PnPsolver RANSAC (the BASELINE metric); poseopt: Optimizer::PoseOptimization, the pose solve the reference's "
+                         "TrackWithMotionModel really calls (SURVEY D1) -- reported under the same metric name with config.pose_solver set")
     args = ap.parse_args()
 
     import torch
@@ -190,8 +197,11 @@ def main():
         if not args.orb_only:
             trk.align(B, 0)
             trk.match(B, 8.0, True, True)
-            trk.pnp(B, PNP["probability"], PNP["min_inliers"], PNP["max_iterations"], PNP["min_set"], PNP["epsilon"],
-                    PNP["th2"], PNP["max_iterations"])
+            if args.pose_solver == "pnp":
+                trk.pnp(B, PNP["probability"], PNP["min_inliers"], PNP["max_iterations"], PNP["min_set"], PNP["epsilon"],
+                        PNP["th2"], PNP["max_iterations"])
+            else:
+                trk.pose_opt(B, 0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -218,7 +228,11 @@ def main():
 
     # ---- results: fixed-size per-frame records (pose + counts), all-gathered across ranks
     al = trk.get_align(0, B)
-    pn = trk.get_pnp(0, B)
+    if args.pose_solver == "pnp" or args.orb_only:
+        pn = trk.get_pnp(0, B)
+    else:
+        po = trk.get_pose_opt(0, B)
+        pn = dict(ok=po["n_inliers"] >= 10, n_inliers=po["n_inliers"], iterations=po["iterations"], N=po["n_initial"])
     cm, nm = trk.get_matches(0, B)
     from sdslam_amd import dist_util
     rec = dist_util.pack_records([t.T.ravel() for t in al["T"]], al["ok"], nm, pn["n_inliers"], pn["ok"])
@@ -229,7 +243,7 @@ def main():
 
     if rank == 0:
         total_frames = B * args.steps * world
-        names = cur.stage_names() + ["image_align", "search_by_projection", "pnp_ransac"]
+        names = cur.stage_names() + ["image_align", "search_by_projection", "pnp_ransac" if args.pose_solver == "pnp" else "pose_optimization"]
         stage_ms = np.concatenate([orb_ms, trk_ms])
         sbytes = list(cur.stage_bytes())
         # algorithmic bytes of the tracking stages, from what this run actually did
@@ -251,7 +265,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("ORB extract only (BASELINE configs[1] without matching)" if args.orb_only else
                                     "BASELINE configs[3] at the configs[1] pyramid: 640x480, 8-level x1.2, 1000 kp; "
-                                    "ORB extract + ImageAlign (levels 4,3,2) + SearchByProjection + PnP RANSAC 200 its"),
+                                    "ORB extract + ImageAlign (levels 4,3,2) + SearchByProjection + " +
+                                    ("PnP RANSAC 200 its" if args.pose_solver == "pnp" else "Optimizer::PoseOptimization (g2o LM, 4x10 its)")),
+                       "pose_solver": args.pose_solver,
                        "frames_per_gpu_per_step": B, "unique_scenes": nu, "inputs": "resident in HBM",
                        "pose_records": "all-gathered over RCCL" if world > 1 else "single GPU"},
             "stages_ms_per_step": {nm_: float(ms) for nm_, ms in zip(names, stage_ms)},
@@ -266,7 +282,7 @@ def main():
                          "mean_pnp_iterations": float(pn["iterations"].mean()), "align_translation_err_m": terr},
         }
         if not args.no_cpu_baseline and world == 1 and not args.orb_only:
-            line["cpu_baseline"] = cpu_baseline(scenes, lasts_u, T0_u, rs)
+            line["cpu_baseline"] = cpu_baseline(scenes, lasts_u, T0_u, rs, pose_solver=args.pose_solver)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line, default=float))

@@ -387,7 +387,10 @@ int sd_track_pose_opt(sd_track* h, int n_frames, int source) {
   hipStream_t s = h->pnp_stream;
   rc = wait_inputs(h, false);
   if (rc != SD_OK) return rc;
+  hipEvent_t* ev = h->ev[h->ev_calls[2] % sd_track::kRing];   // timed in the pose-solve slot, like sd_track_pnp
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[4], s));
   rc = launch_pose_opt(h->cur, h->tb, h->cam, h->d_inv_sigma2, source, n_frames, s);
+  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[5], s)); h->ev_calls[2]++; }
   if (rc == SD_OK) rc = mark_reads(h, false);
   return rc;
 }
