@@ -49,4 +49,13 @@ for seed in (20,):
     np.savez_compressed(os.path.join(OUT, f"track_seed{seed}.npz"), T0=T0, align_T=al["T"], align_iters=al["iters"],
                         align_error=al["error"], align_chi2=al["chi2"], n_matches=nm, cur_match=cm,
                         pnp_T=r["T"], pnp_inliers=r["inliers"], pnp_iterations=r["iterations"], pnp_n_inliers=r["n_inliers"])
+    # stages added after the first fixtures: undistortion, local-map search, PoseOptimization (same scene)
+    Kd, dist = (517.3, 516.5, 318.6, 255.3), (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)
+    und = O.undistort_points(np.stack([ck["x"], ck["y"]], 1), Kd, dist)
+    pts = {k: v[:1000] for k, v in synth.local_map_case(7, ck, cd, s["T_cur"]).items()}
+    lm = O.search_local_points(ck, cd, tab["sf"], np.log(np.float32(1.2)), BOUNDS, K, 0.0, s["T_cur"], pts, th=1.0, nnratio=0.8)
+    po = O.pose_optimization(ck, valid, Xw, tab["inv_sigma2"], K, T0)
+    np.savez_compressed(os.path.join(OUT, f"track2_seed{seed}.npz"), undist=und, lm_match=lm["match"], lm_n=lm["n"],
+                        lm_in_view=lm["in_view"], lm_level=lm["level"], lm_proj=lm["proj"], po_T=po["T"], po_outlier=po["outlier"],
+                        po_n_inliers=po["n_inliers"])
 print("golden written to", OUT, sorted(os.listdir(OUT)))
