@@ -423,3 +423,44 @@ def test_pose_optimization_matches_oracle(sd, oracle, rig):
     for i in range(B):
         assert g["n_inliers"][i] == 0 and g["rounds"][i] == 0 and np.abs(g["T"][i] - T[i]).max() == 0
     trk.set_last(0, [o["last"] for o in rig["oras"]])
+
+
+def test_degenerate_frames_through_the_whole_chain(sd, oracle):
+    """A textureless current frame (0 keypoints), an empty last frame and an empty local map go through every stage
+    without faults and give the reference's 'nothing to do' outcomes; a partial batch (n < max_batch) works."""
+    B = 3
+    sc = synth.make_scene(90, (0.02, -0.01, 0.015), (0.4, -0.3, 0.5))
+    flat = np.full((480, 640), 127, np.uint8)
+    cur = sd.ORBextractor(*CFG, 640, 480, B)
+    ref = sd.ORBextractor(*CFG, 640, 480, B)
+    kps, desc, n = cur.extract_batch(np.stack([flat, sc["cur"]]))          # 2 of 3 frames
+    assert n[0] == 0 and n[1] > 500
+    rk, rd, rn = ref.extract_batch(np.stack([sc["ref"], sc["ref"]]))
+    trk = sd.Tracker(cur, ref, max_points=1000, max_batch=B, pnp_max_iterations=200)
+    trk.set_camera(*K, 0.0, BOUNDS)
+    last = synth.tracking_case(1, rk[0, :rn[0]], rd[0, :rn[0]])
+    empty = {k: v[:0] for k, v in last.items()}
+    trk.set_last(0, [last, empty])
+    trk.set_poses(0, [sc["T_ref"]] * 2, [sc["T_cur"]] * 2)
+    trk.set_rand(0, np.tile(synth.glibc_rand_stream(800), (2, 1)))
+    trk.align(2, 0)
+    al = trk.get_align(0, 2)
+    assert al["ok"][0] and not al["ok"][1]                       # frame 1: "No points to track!" -> false, pose untouched
+    assert np.abs(al["T"][1] - sc["T_cur"]).max() == 0
+    trk.set_poses(0, [sc["T_ref"]] * 2, [sc["T_cur"]] * 2)
+    trk.match(2, 8.0, True, True)
+    cm, nm = trk.get_matches(0, 2)
+    assert nm[0] == 0 and nm[1] == 0 and (cm == -1).all()        # no keypoints / no map points
+    trk.pnp(2, 0.99, 10, 200, 4, 0.28, 5.991, 200)
+    pn = trk.get_pnp(0, 2)
+    assert not pn["ok"].any() and pn["no_more"].all() and (pn["N"] == 0).all()
+    trk.pose_opt(2, 0)
+    po = trk.get_pose_opt(0, 2)
+    assert (po["n_inliers"] == 0).all() and np.abs(po["T"][0] - sc["T_cur"]).max() == 0
+    pts = synth.local_map_case(3, kps[1, :n[1]], desc[1, :n[1]], sc["T_cur"])
+    pts = {k: v[:1000] for k, v in pts.items()}
+    trk.set_local(0, [pts, {k: v[:0] for k, v in pts.items()}])
+    trk.match_local(2, 1.0, 0.8)
+    lm = trk.get_local(0, 2)
+    assert lm["n"][0] == 0 and lm["n"][1] == 0 and (lm["match"] == -1).all()
+    assert lm["in_view"][0].sum() > 500 and not lm["in_view"][1].any()      # points project into the flat frame, nothing to match
