@@ -170,7 +170,7 @@ __device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __rest
 }
 
 // Dynamic LDS layout (KP2 = power of two >= keypoint capacity, MP = max_points):
-//   u32 s_key[KP2] | u32 s_list[MT_LIST_CAP] | u32 s_pt[MP] | f32 s_kang[KP2] | u32 s_obs[(MP+31)/32] |
+//   u32 s_key[KP2] | u32 s_list[MT_LIST_CAP] | u32 s_pt[MP] | f32 s_kang[KP2] | u32 s_obs[(MP+31)/32] | u32 s_valid[(MP+31)/32] |
 //   i16 s_match[KP2] | u16 s_ev[KP2] | u16 s_cstart[64*48+2] | int s_hist[30] | int s_nlist
 __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
                                                           const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
@@ -182,7 +182,8 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
   uint32_t* s_pt = s_list + MT_LIST_CAP;
   float* s_kang = (float*)(s_pt + MP);
   uint32_t* s_obs = (uint32_t*)(s_kang + KP2);
-  int16_t* s_match = (int16_t*)(s_obs + ((MP + 31) >> 5));
+  uint32_t* s_valid = s_obs + ((MP + 31) >> 5);
+  int16_t* s_match = (int16_t*)(s_valid + ((MP + 31) >> 5));
   uint16_t* s_ev = (uint16_t*)(s_match + KP2);
   uint16_t* s_cstart = s_ev + KP2;
   int* s_hist = (int*)(((uintptr_t)(s_cstart + GRID_COLS * GRID_ROWS + 2) + 3) & ~(uintptr_t)3);
@@ -222,13 +223,19 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
     s_kang[i] = ang;
     s_match[i] = -1;   // CurrentFrame.mvpMapPoints filled with NULL (src/Tracking.cc:676)
   }
-  for (int w = tid; w < ((MP + 31) >> 5); w += NT) {   // Observations() > 0 flags of the last frame's points
-    uint32_t bits = 0;
-    for (int k = 0; k < 32; k++) {
-      const int m = w * 32 + k;
-      if (m < n_last && l_obs[m] > 0) bits |= 1u << k;
+  // Observations() > 0 and validity flags of the last frame's points as bit masks: one element per thread, wave ballots
+  for (int m0 = 0; m0 < ((MP + 63) & ~63); m0 += NT) {
+    const int m = m0 + tid;
+    const unsigned long long bo = __ballot(m < n_last && l_obs[m] > 0), bv = __ballot(m < n_last && valid[m] != 0);
+    const int w = (m0 >> 5) + 2 * wave;
+    if (lane == 0 && w < ((MP + 31) >> 5)) {
+      s_obs[w] = (uint32_t)bo;
+      s_valid[w] = (uint32_t)bv;
+      if (w + 1 < ((MP + 31) >> 5)) {
+        s_obs[w + 1] = (uint32_t)(bo >> 32);
+        s_valid[w + 1] = (uint32_t)(bv >> 32);
+      }
     }
-    s_obs[w] = bits;
   }
   if (tid < HISTO_LENGTH) s_hist[tid] = 0;
   if (tid == 0) *s_nlist = 0;
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
     const int i = i0 + wave;
     if (i >= n_last) break;
     uint32_t pc = 0;
-    if (valid[i]) {
+    if ((s_valid[i >> 5] >> (i & 31)) & 1u) {
       int seq = 0;
       const int cnt = (int)match_point<0>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, nullptr, lane, lt, &seq);
       if (cnt > 0) {
@@ -448,21 +455,23 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
     s_koct[i] = (uint8_t)oct;
     s_match[i] = -1;
   }
-  for (int w = tid; w < (KP2 >> 5); w += NT) {
-    uint32_t bits = 0;
-    for (int k = 0; k < 32; k++) {
-      const int i = w * 32 + k;
-      if (i < N && kclaim[i]) bits |= 1u << k;
+  for (int i0 = 0; i0 < KP2; i0 += NT) {   // claim flags / Observations() > 0 flags as bit masks (wave ballots)
+    const int i = i0 + tid;
+    const unsigned long long bc = __ballot(i < N && kclaim[i] != 0);
+    const int w = (i0 >> 5) + 2 * wave;
+    if (lane == 0 && w < (KP2 >> 5)) {
+      s_kclaim[w] = (uint32_t)bc;
+      if (w + 1 < (KP2 >> 5)) s_kclaim[w + 1] = (uint32_t)(bc >> 32);
     }
-    s_kclaim[w] = bits;
   }
-  for (int w = tid; w < ((MP + 31) >> 5); w += NT) {
-    uint32_t bits = 0;
-    for (int k = 0; k < 32; k++) {
-      const int m = w * 32 + k;
-      if (m < n_loc && l_obs[m] > 0) bits |= 1u << k;
+  for (int m0 = 0; m0 < ((MP + 63) & ~63); m0 += NT) {
+    const int m = m0 + tid;
+    const unsigned long long bo = __ballot(m < n_loc && l_obs[m] > 0);
+    const int w = (m0 >> 5) + 2 * wave;
+    if (lane == 0 && w < ((MP + 31) >> 5)) {
+      s_obs[w] = (uint32_t)bo;
+      if (w + 1 < ((MP + 31) >> 5)) s_obs[w + 1] = (uint32_t)(bo >> 32);
     }
-    s_obs[w] = bits;
   }
   if (tid == 0) *s_nlist = 0;
   __syncthreads();
@@ -683,7 +692,7 @@ int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam,
   while (KP2 < tb.kp_cap) KP2 <<= 1;
   SD_REQUIRE(KP2 <= MT_MAXKP && tb.max_points <= 2048, SD_ERR_CAPACITY, "matcher supports at most 2048 keypoints / map points per frame");
   const int MP = tb.max_points;
-  const size_t lds = (size_t)KP2 * 4 + MT_LIST_CAP * 4 + (size_t)MP * 4 + (size_t)KP2 * 4 + (size_t)((MP + 31) >> 5) * 4 + (size_t)KP2 * 2 +
+  const size_t lds = (size_t)KP2 * 4 + MT_LIST_CAP * 4 + (size_t)MP * 4 + (size_t)KP2 * 4 + (size_t)((MP + 31) >> 5) * 8 + (size_t)KP2 * 2 +
                      (size_t)KP2 * 2 + (GRID_COLS * GRID_ROWS + 2) * 2 + 4 + (HISTO_LENGTH + 1) * 4;
   hipLaunchKernelGGL(k_match, dim3(n_frames), dim3(64 * MT_WAVES), lds, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_desc,
                      cur->d_nout, tb, cam, d_sf, th, mono, check_ori, KP2);
