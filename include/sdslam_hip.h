@@ -114,6 +114,10 @@ int sd_orb_stage_bytes(const sd_orb* h, double* bytes_out, int cap);
 
 /* device memory helpers for harnesses that have no HIP binding of their own */
 int sd_dev_alloc(size_t bytes, void** out);
+/* page-locked host buffers (hipHostMalloc): frames handed to sd_orb_extract / sd_orb_extract_batch from such a buffer
+ * are copied at the PCIe rate instead of through the driver's pageable-memory staging */
+int sd_host_alloc(size_t bytes, void** out);
+int sd_host_free(void* p);
 int sd_dev_free(void* p);
 int sd_dev_upload(void* dst, const void* src, size_t bytes);
 int sd_dev_download(void* dst, const void* src, size_t bytes);

@@ -110,6 +110,29 @@ def plan_info(nfeatures, scale_factor, nlevels, th_fast, w, h):
     return dict(levels=lv, cells=zones[:n.value].copy(), bytes_per_frame=nbytes.value)
 
 
+def pinned_array(shape, dtype=np.uint8):
+    """numpy array over page-locked host memory (sd_host_alloc); keep the returned owner alive."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    L = lib()
+    p = C.c_void_p()
+    L.sd_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    _check(L.sd_host_alloc(n, C.byref(p)))
+    buf = (C.c_uint8 * n).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    class _Owner:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def __del__(self):
+            try:
+                L.sd_host_free.argtypes = [C.c_void_p]
+                L.sd_host_free(self.ptr)
+            except Exception:
+                pass
+    return arr, _Owner(p)
+
+
 class DeviceBuffer:
     """Raw HBM allocation (for harnesses that stage inputs on the device themselves)."""
 
