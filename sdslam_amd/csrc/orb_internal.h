@@ -61,6 +61,18 @@ struct sd_orb {
   uint8_t* d_desc = nullptr;
   int32_t* d_nout = nullptr;
   size_t cap_pyr = 0, cap_cand = 0, cap_cells = 0, cap_tiles = 0, cap_coef = 0;
+  // hipGraph cache of the extraction pipeline (multi-stream fork/join captured once per argument set); opt-in with
+  // SD_USE_GRAPH=1 -- see launch_pipeline for the measurement that keeps direct launches the default
+  struct GraphEntry {
+    const void* imgs = nullptr;
+    int n = 0, stride = 0, set = -1;
+    size_t frame_stride = 0;
+    bool dist = false;
+    float distv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    hipGraphExec_t exec = nullptr;
+  };
+  GraphEntry graphs[4];
+  int graph_next = 0;
   bool profiling = false;
   // ring of per-call stage events: the bench reads mean stage times over its whole timed region
   static const int kRing = 128;
