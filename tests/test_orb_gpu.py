@@ -152,3 +152,36 @@ def test_undistort_keypoints_bit_exact(sd, oracle):
     un2 = ext.download_undistorted(0, 2)
     for i in range(2):
         assert np.array_equal(un2[i, :n2[i]], kps2[i, :n2[i]])
+
+
+def test_hipgraph_replay_matches_direct_launches(sd, oracle):
+    """SD_USE_GRAPH=1 (captured multi-stream pipeline replayed as one hipGraph): same bits as direct launches, on
+    first capture and on replays, after a geometry change and with a second argument set."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+import sdslam_amd
+from sdslam_amd.synth import make_image
+from oracle import oracle
+ext = sdslam_amd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2)
+ora = oracle.OrbOracle(1000, 1.2, 8, 20)
+imgs = np.stack([make_image(3), make_image(4)])
+exp = [ora.extract(im) for im in imgs]
+for rep in range(3):                       # capture, replay, replay
+    k, d, n = ext.extract_batch(imgs)
+    for i in range(2):
+        assert np.array_equal(k[i, :n[i]], exp[i][0]) and np.array_equal(d[i, :n[i]], exp[i][1]), (rep, i)
+small = make_image(5)[:240, :320].copy()    # geometry change drops the graphs
+ks, ds = ext(small)
+es = oracle.OrbOracle(1000, 1.2, 8, 20).extract(small)
+assert np.array_equal(ks, es[0]) and np.array_equal(ds, es[1])
+k, d, n = ext.extract_batch(imgs[:1])       # different batch size: new capture
+assert np.array_equal(k[0, :n[0]], exp[0][0])
+print("graph ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SD_USE_GRAPH="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "graph ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
