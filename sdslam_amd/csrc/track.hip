@@ -263,8 +263,12 @@ int sd_track_set_rand(sd_track* h, int frame0, int n_frames, const int32_t* rand
 }
 
 // Order the tracking stream behind the extractions it consumes ...
-static int wait_inputs(sd_track* h, bool need_ref) {
-  if (h->cur->extract_recorded) SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, h->cur->ev_extract_done, 0));
+static int wait_inputs(sd_track* h, bool need_ref, bool pyramid_only = false) {
+  // ImageAlign reads pyramids only: it may start as soon as the current batch's pyramid exists, beside FAST / selection /
+  // descriptors of the same batch (SD_ALIGN_EARLY=0 restores the wait for the whole extraction)
+  static const bool early = !(getenv("SD_ALIGN_EARLY") && getenv("SD_ALIGN_EARLY")[0] == '0');
+  if (h->cur->extract_recorded)
+    SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, (pyramid_only && early) ? h->cur->ev_pyr_done : h->cur->ev_extract_done, 0));
   if (need_ref && h->ref->extract_recorded) SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, h->ref->ev_extract_done, 0));
   return SD_OK;
 }
@@ -297,7 +301,7 @@ int sd_track_align(sd_track* h, int n_frames, int mode) {
   SD_REQUIRE(h->ref->have_geom && h->ref->last_frames >= n_frames && h->ref->cur_w == h->cur->cur_w && h->ref->cur_h == h->cur->cur_h,
              SD_ERR_INVALID_ARG, "reference frames not extracted or of different size");
   hipStream_t s = h->pnp_stream;
-  rc = wait_inputs(h, true);
+  rc = wait_inputs(h, true, true);
   if (rc != SD_OK) return rc;
   hipEvent_t* ev = h->ev[h->ev_calls[0] % sd_track::kRing];
   if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[0], s));
