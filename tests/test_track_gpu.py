@@ -464,3 +464,35 @@ def test_degenerate_frames_through_the_whole_chain(sd, oracle):
     lm = trk.get_local(0, 2)
     assert lm["n"][0] == 0 and lm["n"][1] == 0 and (lm["match"] == -1).all()
     assert lm["in_view"][0].sum() > 500 and not lm["in_view"][1].any()      # points project into the flat frame, nothing to match
+
+
+def test_tracker_errors_are_loud(sd):
+    """Capacity / argument violations come back as SdError, never as silent truncation."""
+    cur = sd.ORBextractor(*CFG, 640, 480, 2)
+    ref = sd.ORBextractor(*CFG, 640, 480, 2)
+    trk = sd.Tracker(cur, ref, max_points=100, max_batch=2, pnp_max_iterations=50)
+    with pytest.raises(sd.SdError):
+        trk.align(1, 0)                                   # camera not set
+    trk.set_camera(*K, 0.0, BOUNDS)
+    with pytest.raises(sd.SdError):
+        trk.align(1, 0)                                   # nothing extracted yet
+    img = synth.make_image(1)
+    cur.extract_batch(img[None])
+    ref.extract_batch(img[None])
+    with pytest.raises(sd.SdError):
+        trk.align(2, 0)                                   # only one frame was extracted
+    with pytest.raises(sd.SdError):
+        trk.align(1, 7)                                   # bad mode
+    with pytest.raises(sd.SdError):
+        trk.pnp(1, 0.99, 10, 300, 4, 0.4, 5.991, 300)     # iterations exceed the handle's pnp_max_iterations
+    with pytest.raises(sd.SdError):
+        trk.pnp(1, 0.99, 10, 50, 5, 0.4, 5.991, 50)       # minSet != 4
+    with pytest.raises(sd.SdError):
+        trk.pose_opt(1, source=2)
+    big = dict(cand=np.ones(101, np.uint8), Xw=np.zeros((101, 3)), normal=np.zeros((101, 3)), min_dist=np.zeros(101, np.float32),
+               max_dist=np.ones(101, np.float32), mf_max_dist=np.ones(101, np.float32), desc=np.zeros((101, 32), np.uint8),
+               obs=np.zeros(101, np.int32))
+    with pytest.raises((sd.SdError, ValueError)):
+        trk.set_local(0, [big])                           # more local points than max_points
+    with pytest.raises(sd.SdError):
+        sd.Tracker(cur, ref, max_points=5000, max_batch=2)   # beyond the matcher's index width
