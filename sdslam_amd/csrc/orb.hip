@@ -925,87 +925,125 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
   const int frame = (t / bpf) * 8 + xcd, blk = t % bpf;
   if (frame >= n_frames) return;
   const int lane = threadIdx.x & 63;
-  int g = blk * 4 + (threadIdx.x >> 6);   // output slot of this wave
-  // locate (level, index) from the per-level counts (uniform scalar loop)
+  // Two keypoints per wave, interleaved: the kernel is a chain of dependent gathers (key -> 31 x 31 patch -> angle ->
+  // 512 sample points), so a wave with two independent chains in flight keeps twice the loads outstanding.
+  const int g0 = (blk * 4 + (threadIdx.x >> 6)) * 2;   // output slots g0, g0 + 1
   const int32_t* sc = sel_count + (size_t)frame * P->nlevels;
-  int level = -1, idx = 0, acc = 0;
+  int level[2] = {-1, -1}, idx[2] = {0, 0}, acc = 0;
   for (int l = 0; l < P->nlevels; l++) {
-    int n = sc[l];
-    if (level < 0 && g < acc + n) {
-      level = l;
-      idx = g - acc;
-    }
+    const int n = sc[l];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      if (level[q] < 0 && g0 + q < acc + n) {
+        level[q] = l;
+        idx[q] = g0 + q - acc;
+      }
     acc += n;
   }
   if (blk == 0 && threadIdx.x == 0) nout[frame] = min(acc, cap);
-  if (level < 0 || g >= cap) return;
-  const LevelGeom L = P->lv[level];
-  const uint32_t key = sel[(size_t)frame * P->nsel + L.sel_off + idx];
-  const int X = key & 0xfff, Y = (key >> 12) & 0xfff, resp = key >> 24;
-  const size_t fo = (size_t)frame * P->pyr_frame_bytes + L.off;
-  const int step = L.pstride;
-  const uint8_t* center = pyr + fo + (size_t)(Y + SD_EDGE) * step + X + SD_EDGE;
+  bool live[2];
+  int X[2], Y[2], resp[2], step[2];
+  const uint8_t* center[2];
+  const uint8_t* bc[2];
+  float scale[2], kpsize[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    live[q] = level[q] >= 0 && g0 + q < cap;
+    const int lv = live[q] ? level[q] : 0;
+    const LevelGeom& L = P->lv[lv];
+    const uint32_t key = live[q] ? sel[(size_t)frame * P->nsel + L.sel_off + idx[q]] : 0u;
+    X[q] = live[q] ? (int)(key & 0xfff) : SD_EDGE;     // dead slot: a harmless in-range position
+    Y[q] = live[q] ? (int)((key >> 12) & 0xfff) : SD_EDGE;
+    resp[q] = key >> 24;
+    step[q] = L.pstride;
+    scale[q] = L.scale;
+    kpsize[q] = L.kpsize;
+    const size_t fo = (size_t)frame * P->pyr_frame_bytes + L.off + (size_t)(Y[q] + SD_EDGE) * L.pstride + X[q] + SD_EDGE;
+    center[q] = pyr + fo;
+    bc[q] = blur + fo;
+  }
+  if (!live[0]) return;   // slots are filled in order: no first keypoint, no second
 
   // ---- IC_Angle
-  int m10 = 0, m01 = 0;
+  int m10[2] = {0, 0}, m01[2] = {0, 0};
   {
     const int u = (lane & 31) - 15;
     const int half = lane >> 5;   // 0: rows +v, 1: rows -v
     const bool act = (lane & 31) < 31;
     const int au = abs(u);
-    const int sstep = half ? -step : step;
 #pragma unroll
-    for (int v = 0; v <= 15; v++) {   // fully unrolled: the 16 row loads are independent and issue back to back
+    for (int v = 0; v <= 15; v++) {   // fully unrolled: the 2 x 16 row loads are independent and issue back to back
       if (act && au <= c_umax[v] && !(half && v == 0)) {
-        const int val = center[u + v * sstep];
-        m10 += u * val;
-        m01 += (half ? -v : v) * val;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int val = center[q][u + v * (half ? -step[q] : step[q])];
+          m10[q] += u * val;
+          m01[q] += (half ? -v : v) * val;
+        }
       }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      m10 += __shfl_xor(m10, o);
-      m01 += __shfl_xor(m01, o);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        m10[q] += __shfl_xor(m10[q], o);
+        m01[q] += __shfl_xor(m01[q], o);
+      }
     }
   }
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-
   // ---- steered rBRIEF on the blurred level
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  const float arad = angle * factorPI;
-  const float a = sdsc::cosf_glibc(arad), b = sdsc::sinf_glibc(arad);
-  const uint8_t* bc = blur + fo + (size_t)(Y + SD_EDGE) * step + X + SD_EDGE;
-  unsigned long long words[4];
+  float angle[2], ca[2], sb[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    angle[q] = fast_atan2_deg((float)m01[q], (float)m10[q]);
+    const float arad = angle[q] * factorPI;
+    ca[q] = sdsc::cosf_glibc(arad);
+    sb[q] = sdsc::sinf_glibc(arad);
+  }
+  unsigned long long words[2][4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int t = j * 64 + lane;
     const char4 pt = *(const char4*)(&c_pattern[t * 4]);
     const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
-    // center[cvRound(x*b + y*a)*step + cvRound(x*a - y*b)]
-    const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
-    const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
-    const int t0 = bc[__mul24(r0, step) + q0], t1 = bc[__mul24(r1, step) + q1];
-    words[j] = __ballot(t0 < t1);
-  }
-  if (lane < 4) {
-    unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-    *(unsigned long long*)(desc + ((size_t)frame * cap + g) * 32 + lane * 8) = w;
-  }
-  if (lane == 0) {
-    sd_keypoint k;
-    float fx = (float)X, fy = (float)Y;
-    if (level != 0) {
-      fx = fx * L.scale;
-      fy = fy * L.scale;
+    int t0[2], t1[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const float a = ca[q], b = sb[q];
+      // center[cvRound(x*b + y*a)*step + cvRound(x*a - y*b)]
+      const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
+      const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
+      t0[q] = bc[q][__mul24(r0, step[q]) + q0];
+      t1[q] = bc[q][__mul24(r1, step[q]) + q1];
     }
-    k.x = fx;
-    k.y = fy;
-    k.size = L.kpsize;
-    k.angle = angle;
-    k.response = (float)resp;
-    k.octave = level;
-    k.class_id = -1;
-    kps[(size_t)frame * cap + g] = k;
+#pragma unroll
+    for (int q = 0; q < 2; q++) words[q][j] = __ballot(t0[q] < t1[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if (!live[q]) continue;
+    const int g = g0 + q;
+    if (lane < 4) {
+      unsigned long long w = lane == 0 ? words[q][0] : lane == 1 ? words[q][1] : lane == 2 ? words[q][2] : words[q][3];
+      *(unsigned long long*)(desc + ((size_t)frame * cap + g) * 32 + lane * 8) = w;
+    }
+    if (lane == 0) {
+      sd_keypoint k;
+      float fx = (float)X[q], fy = (float)Y[q];
+      if (level[q] != 0) {
+        fx = fx * scale[q];
+        fy = fy * scale[q];
+      }
+      k.x = fx;
+      k.y = fy;
+      k.size = kpsize[q];
+      k.angle = angle[q];
+      k.response = (float)resp[q];
+      k.octave = level[q];
+      k.class_id = -1;
+      kps[(size_t)frame * cap + g] = k;
+    }
   }
 }
 
@@ -1193,7 +1231,7 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[4], s));
   const int cap = std::max(P.nsel, 1);
   {
-    const int bpf = (cap + 3) / 4;
+    const int bpf = (cap + 7) / 8;   // 4 waves x 2 keypoints per workgroup
     hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)(((n + 7) / 8) * 8 * bpf)), dim3(256), 0, s, h->d_plan, h->d_pyr, h->d_blur,
                        h->d_sel, h->d_sel_count, h->d_kps, h->d_desc, h->d_nout, cap, n, bpf);
   }
