@@ -910,6 +910,9 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
+#ifndef DESC_KPW
+#define DESC_KPW 2   // keypoints per wave
+#endif
 __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr,
                                                      const uint8_t* __restrict__ blur,
                                                      const uint32_t* __restrict__ sel,
@@ -927,13 +930,15 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
   const int lane = threadIdx.x & 63;
   // Two keypoints per wave, interleaved: the kernel is a chain of dependent gathers (key -> 31 x 31 patch -> angle ->
   // 512 sample points), so a wave with two independent chains in flight keeps twice the loads outstanding.
-  const int g0 = (blk * 4 + (threadIdx.x >> 6)) * 2;   // output slots g0, g0 + 1
+  const int g0 = (blk * 4 + (threadIdx.x >> 6)) * DESC_KPW;   // output slots g0 .. g0 + DESC_KPW - 1
   const int32_t* sc = sel_count + (size_t)frame * P->nlevels;
-  int level[2] = {-1, -1}, idx[2] = {0, 0}, acc = 0;
+  int level[DESC_KPW], idx[DESC_KPW], acc = 0;
+#pragma unroll
+  for (int q = 0; q < DESC_KPW; q++) { level[q] = -1; idx[q] = 0; }
   for (int l = 0; l < P->nlevels; l++) {
     const int n = sc[l];
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < DESC_KPW; q++)
       if (level[q] < 0 && g0 + q < acc + n) {
         level[q] = l;
         idx[q] = g0 + q - acc;
@@ -941,13 +946,13 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
     acc += n;
   }
   if (blk == 0 && threadIdx.x == 0) nout[frame] = min(acc, cap);
-  bool live[2];
-  int X[2], Y[2], resp[2], step[2];
-  const uint8_t* center[2];
-  const uint8_t* bc[2];
-  float scale[2], kpsize[2];
+  bool live[DESC_KPW];
+  int X[DESC_KPW], Y[DESC_KPW], resp[DESC_KPW], step[DESC_KPW];
+  const uint8_t* center[DESC_KPW];
+  const uint8_t* bc[DESC_KPW];
+  float scale[DESC_KPW], kpsize[DESC_KPW];
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
+  for (int q = 0; q < DESC_KPW; q++) {
     live[q] = level[q] >= 0 && g0 + q < cap;
     const int lv = live[q] ? level[q] : 0;
     const LevelGeom& L = P->lv[lv];
@@ -965,7 +970,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
   if (!live[0]) return;   // slots are filled in order: no first keypoint, no second
 
   // ---- IC_Angle
-  int m10[2] = {0, 0}, m01[2] = {0, 0};
+  int m10[DESC_KPW], m01[DESC_KPW];
+#pragma unroll
+  for (int q = 0; q < DESC_KPW; q++) m10[q] = m01[q] = 0;
   {
     const int u = (lane & 31) - 15;
     const int half = lane >> 5;   // 0: rows +v, 1: rows -v
@@ -975,7 +982,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
     for (int v = 0; v <= 15; v++) {   // fully unrolled: the 2 x 16 row loads are independent and issue back to back
       if (act && au <= c_umax[v] && !(half && v == 0)) {
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < DESC_KPW; q++) {
           const int val = center[q][u + v * (half ? -step[q] : step[q])];
           m10[q] += u * val;
           m01[q] += (half ? -v : v) * val;
@@ -985,7 +992,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
+      for (int q = 0; q < DESC_KPW; q++) {
         m10[q] += __shfl_xor(m10[q], o);
         m01[q] += __shfl_xor(m01[q], o);
       }
@@ -993,23 +1000,23 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
   }
   // ---- steered rBRIEF on the blurred level
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  float angle[2], ca[2], sb[2];
+  float angle[DESC_KPW], ca[DESC_KPW], sb[DESC_KPW];
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
+  for (int q = 0; q < DESC_KPW; q++) {
     angle[q] = fast_atan2_deg((float)m01[q], (float)m10[q]);
     const float arad = angle[q] * factorPI;
     ca[q] = sdsc::cosf_glibc(arad);
     sb[q] = sdsc::sinf_glibc(arad);
   }
-  unsigned long long words[2][4];
+  unsigned long long words[DESC_KPW][4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int t = j * 64 + lane;
     const char4 pt = *(const char4*)(&c_pattern[t * 4]);
     const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
-    int t0[2], t1[2];
+    int t0[DESC_KPW], t1[DESC_KPW];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < DESC_KPW; q++) {
       const float a = ca[q], b = sb[q];
       // center[cvRound(x*b + y*a)*step + cvRound(x*a - y*b)]
       const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
@@ -1018,10 +1025,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
       t1[q] = bc[q][__mul24(r1, step[q]) + q1];
     }
 #pragma unroll
-    for (int q = 0; q < 2; q++) words[q][j] = __ballot(t0[q] < t1[q]);
+    for (int q = 0; q < DESC_KPW; q++) words[q][j] = __ballot(t0[q] < t1[q]);
   }
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
+  for (int q = 0; q < DESC_KPW; q++) {
     if (!live[q]) continue;
     const int g = g0 + q;
     if (lane < 4) {
@@ -1231,7 +1238,7 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[4], s));
   const int cap = std::max(P.nsel, 1);
   {
-    const int bpf = (cap + 7) / 8;   // 4 waves x 2 keypoints per workgroup
+    const int bpf = (cap + 4 * DESC_KPW - 1) / (4 * DESC_KPW);   // 4 waves x DESC_KPW keypoints per workgroup
     hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)(((n + 7) / 8) * 8 * bpf)), dim3(256), 0, s, h->d_plan, h->d_pyr, h->d_blur,
                        h->d_sel, h->d_sel_count, h->d_kps, h->d_desc, h->d_nout, cap, n, bpf);
   }
