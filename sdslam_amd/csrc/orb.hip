@@ -245,23 +245,35 @@ __global__ __launch_bounds__(256) void k_pyr_level(const LevelGeom L, const Leve
 //   k_pyr_rows    top / bottom border rows: copies of (complete) interior rows.
 // Level 0 is the frame copied into the padded layout by the same three kernels.
 // ------------------------------------------------------------------------------------------
+#define PYR_RPT 2   // rows per thread: rows Y and Y + ceil(h / 2) share the x coefficients and give two independent load chains
 __global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const LevelGeom S, size_t pyr_frame_bytes, int level,
                                                     const int32_t* __restrict__ coef, const uint8_t* __restrict__ src0,
                                                     int src_stride, size_t src_frame_stride, uint8_t* __restrict__ pyr,
-                                                    int G, unsigned magicG) {
+                                                    int G, unsigned magicG, int Hh) {
   const int frame = blockIdx.y;
   const unsigned e = blockIdx.x * 256 + threadIdx.x;
-  const unsigned Y = __umulhi(e, magicG);        // e / G
-  if (Y >= (unsigned)L.h) return;
-  const int g = (int)(e - Y * (unsigned)G);
+  const unsigned Y0 = __umulhi(e, magicG);        // e / G
+  if (Y0 >= (unsigned)Hh) return;
+  const int g = (int)(e - Y0 * (unsigned)G);
   const int X0 = 1 + 4 * g;
-  uint8_t* dst = pyr + (size_t)frame * pyr_frame_bytes + L.off + (size_t)(Y + SD_EDGE) * L.pstride + (X0 + SD_EDGE);
-  uint32_t packed;
+  uint8_t* dstb = pyr + (size_t)frame * pyr_frame_bytes + L.off + (size_t)SD_EDGE * L.pstride + (X0 + SD_EDGE);
+  uint32_t packed[PYR_RPT];
+  bool live[PYR_RPT];
+  int Yr[PYR_RPT];
+#pragma unroll
+  for (int r = 0; r < PYR_RPT; r++) {
+    Yr[r] = (int)Y0 + r * Hh;
+    live[r] = Yr[r] < L.h;
+    if (!live[r]) Yr[r] = (int)Y0;   // duplicate work, not stored
+  }
   if (level == 0) {
-    const uint8_t* s = src0 + (size_t)frame * src_frame_stride + (size_t)Y * src_stride + X0;
-    const uintptr_t a = (uintptr_t)s;
-    const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
-    packed = __builtin_amdgcn_alignbyte(q[1], q[0], (unsigned)(a & 3));
+#pragma unroll
+    for (int r = 0; r < PYR_RPT; r++) {
+      const uint8_t* s = src0 + (size_t)frame * src_frame_stride + (size_t)Yr[r] * src_stride + X0;
+      const uintptr_t a = (uintptr_t)s;
+      const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+      packed[r] = __builtin_amdgcn_alignbyte(q[1], q[0], (unsigned)(a & 3));
+    }
   } else {
     const int32_t* xo = coef + L.cx;
     const int32_t* xa = xo + L.w;
@@ -274,23 +286,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const Lev
       sx[k] = xo[X0 + k];
       ab[k] = (uint32_t)xa[X0 + k];
     }
-    int sy0 = yo[Y];
-    const uint32_t bb = (uint32_t)yb[Y];
-    const int b0 = (int)(bb & 0xffff), b1 = (int)(bb >> 16);
-    int sy1 = sy0 + 1;
-    sy0 = sy0 < S.h ? sy0 : S.h - 1;
-    sy1 = sy1 < S.h ? sy1 : S.h - 1;
-    const uint8_t* sb = pyr + (size_t)frame * pyr_frame_bytes + S.off + (size_t)SD_EDGE * S.pstride + SD_EDGE;
     const int base = sx[0];
-    const uintptr_t a0 = (uintptr_t)(sb + (size_t)__mul24(sy0, S.pstride) + base);
-    const uintptr_t a1 = (uintptr_t)(sb + (size_t)__mul24(sy1, S.pstride) + base);
-    const unsigned sh = (unsigned)(a0 & 3);   // same for both rows: the row pitch is a multiple of 64
-    const uint32_t* q0 = (const uint32_t*)(a0 & ~(uintptr_t)3);
-    const uint32_t* q1 = (const uint32_t*)(a1 & ~(uintptr_t)3);
-    const uint32_t u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
-    // 8 source bytes starting at sx[0], per row
-    const uint32_t r0lo = __builtin_amdgcn_alignbyte(u1, u0, sh), r0hi = __builtin_amdgcn_alignbyte(u2, u1, sh);
-    const uint32_t r1lo = __builtin_amdgcn_alignbyte(v1, v0, sh), r1hi = __builtin_amdgcn_alignbyte(v2, v1, sh);
     uint32_t selA = 0, selB = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -299,21 +295,53 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const Lev
       selA |= (uint32_t)o << (8 * k);
       selB |= (uint32_t)o1 << (8 * k);
     }
-    const uint32_t p0a = __builtin_amdgcn_perm(r0hi, r0lo, selA), p0b = __builtin_amdgcn_perm(r0hi, r0lo, selB);
-    const uint32_t p1a = __builtin_amdgcn_perm(r1hi, r1lo, selA), p1b = __builtin_amdgcn_perm(r1hi, r1lo, selB);
-    packed = 0;
+    const uint8_t* sb = pyr + (size_t)frame * pyr_frame_bytes + S.off + (size_t)SD_EDGE * S.pstride + SD_EDGE;
+    uint32_t u[PYR_RPT][3], v[PYR_RPT][3], bbv[PYR_RPT];
+    unsigned shv[PYR_RPT];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int wa0 = (int)(ab[k] & 0xffff), wa1 = (int)(ab[k] >> 16);
-      const int p00 = (int)((p0a >> (8 * k)) & 0xff), p01 = (int)((p0b >> (8 * k)) & 0xff);
-      const int p10 = (int)((p1a >> (8 * k)) & 0xff), p11 = (int)((p1b >> (8 * k)) & 0xff);
-      const int h0 = __mul24(p00, wa0) + __mul24(p01, wa1);
-      const int h1 = __mul24(p10, wa0) + __mul24(p11, wa1);
-      const int ov = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
-      packed |= (uint32_t)(ov < 0 ? 0 : (ov > 255 ? 255 : ov)) << (8 * k);
+    for (int r = 0; r < PYR_RPT; r++) {   // all loads of both rows first
+      int sy0 = yo[Yr[r]];
+      bbv[r] = (uint32_t)yb[Yr[r]];
+      int sy1 = sy0 + 1;
+      sy0 = sy0 < S.h ? sy0 : S.h - 1;
+      sy1 = sy1 < S.h ? sy1 : S.h - 1;
+      const uintptr_t a0 = (uintptr_t)(sb + (size_t)__mul24(sy0, S.pstride) + base);
+      const uintptr_t a1 = (uintptr_t)(sb + (size_t)__mul24(sy1, S.pstride) + base);
+      shv[r] = (unsigned)(a0 & 3);   // same for both source rows: the row pitch is a multiple of 64
+      const uint32_t* q0 = (const uint32_t*)(a0 & ~(uintptr_t)3);
+      const uint32_t* q1 = (const uint32_t*)(a1 & ~(uintptr_t)3);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        u[r][k] = q0[k];
+        v[r][k] = q1[k];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < PYR_RPT; r++) {
+      const int b0 = (int)(bbv[r] & 0xffff), b1 = (int)(bbv[r] >> 16);
+      const unsigned sh = shv[r];
+      // 8 source bytes starting at sx[0], per row
+      const uint32_t r0lo = __builtin_amdgcn_alignbyte(u[r][1], u[r][0], sh), r0hi = __builtin_amdgcn_alignbyte(u[r][2], u[r][1], sh);
+      const uint32_t r1lo = __builtin_amdgcn_alignbyte(v[r][1], v[r][0], sh), r1hi = __builtin_amdgcn_alignbyte(v[r][2], v[r][1], sh);
+      const uint32_t p0a = __builtin_amdgcn_perm(r0hi, r0lo, selA), p0b = __builtin_amdgcn_perm(r0hi, r0lo, selB);
+      const uint32_t p1a = __builtin_amdgcn_perm(r1hi, r1lo, selA), p1b = __builtin_amdgcn_perm(r1hi, r1lo, selB);
+      uint32_t pk = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int wa0 = (int)(ab[k] & 0xffff), wa1 = (int)(ab[k] >> 16);
+        const int p00 = (int)((p0a >> (8 * k)) & 0xff), p01 = (int)((p0b >> (8 * k)) & 0xff);
+        const int p10 = (int)((p1a >> (8 * k)) & 0xff), p11 = (int)((p1b >> (8 * k)) & 0xff);
+        const int h0 = __mul24(p00, wa0) + __mul24(p01, wa1);
+        const int h1 = __mul24(p10, wa0) + __mul24(p11, wa1);
+        const int ov = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
+        pk |= (uint32_t)(ov < 0 ? 0 : (ov > 255 ? 255 : ov)) << (8 * k);
+      }
+      packed[r] = pk;
     }
   }
-  *(uint32_t*)dst = packed;
+#pragma unroll
+  for (int r = 0; r < PYR_RPT; r++)
+    if (live[r]) *(uint32_t*)(dstb + (size_t)Yr[r] * L.pstride) = packed[r];
 }
 
 // interior rows: padded columns [0, 20) and [20 + 4 G, roundup4(w + 38)); one thread per 4 columns
@@ -1198,8 +1226,9 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
     const int G = (L.w - 1) / 4;
     const int T = 5 + (((L.w + 2 * SD_EDGE + 3) & ~3) - 20 - 4 * G) / 4;
     const int wpr = ((L.w + 2 * SD_EDGE + 3) & ~3) / 4;
-    hipLaunchKernelGGL(k_pyr_resize, dim3((unsigned)(((size_t)L.h * G + 255) / 256), n), dim3(256), 0, s, L, S, (size_t)P.pyr_frame_bytes,
-                       l, h->d_coef, d_imgs, stride, frame_stride, h->d_pyr, G, magic((unsigned)G));
+    const int Hh = (L.h + PYR_RPT - 1) / PYR_RPT;
+    hipLaunchKernelGGL(k_pyr_resize, dim3((unsigned)(((size_t)Hh * G + 255) / 256), n), dim3(256), 0, s, L, S, (size_t)P.pyr_frame_bytes,
+                       l, h->d_coef, d_imgs, stride, frame_stride, h->d_pyr, G, magic((unsigned)G), Hh);
     hipLaunchKernelGGL(k_pyr_edges, dim3((unsigned)(((size_t)L.h * T + 255) / 256), n), dim3(256), 0, s, L, S, (size_t)P.pyr_frame_bytes,
                        l, d_imgs, stride, frame_stride, h->d_pyr, G, T, magic((unsigned)T));
     hipLaunchKernelGGL(k_pyr_rows, dim3((unsigned)((2 * SD_EDGE * wpr + 255) / 256), n), dim3(256), 0, s, L, (size_t)P.pyr_frame_bytes,
