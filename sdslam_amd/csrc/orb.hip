@@ -245,7 +245,10 @@ __global__ __launch_bounds__(256) void k_pyr_level(const LevelGeom L, const Leve
 //   k_pyr_rows    top / bottom border rows: copies of (complete) interior rows.
 // Level 0 is the frame copied into the padded layout by the same three kernels.
 // ------------------------------------------------------------------------------------------
-#define PYR_RPT 2   // rows per thread: rows Y and Y + ceil(h / 2) share the x coefficients and give two independent load chains
+#ifndef PYR_RPT
+#define PYR_RPT 2
+#endif
+// rows per thread: rows Y and Y + ceil(h / 2) share the x coefficients and give two independent load chains
 __global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const LevelGeom S, size_t pyr_frame_bytes, int level,
                                                     const int32_t* __restrict__ coef, const uint8_t* __restrict__ src0,
                                                     int src_stride, size_t src_frame_stride, uint8_t* __restrict__ pyr,
