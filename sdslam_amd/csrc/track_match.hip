@@ -27,7 +27,7 @@
 namespace sd {
 
 #define MT_MAXKP 2048      // keypoints per frame supported by the 11-bit index fields
-#define MT_WAVES 4
+#define MT_WAVES 8
 #define MT_LIST_CAP 4096   // candidate keys per frame kept in LDS (more: per-point slow path)
 #define GRID_COLS 64
 #define GRID_ROWS 48
