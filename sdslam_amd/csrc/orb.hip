@@ -692,7 +692,7 @@ __device__ unsigned long long g_sel_prof[64];
 #define SPROF(i)
 #endif
 
-#define SEL_WAVES 4
+#define SEL_WAVES 8
 #define SEL_CELL_CAP 1024   // candidates of one cell staged per wave (LDS)
 #define SEL_LIST_CAP 1536   // level list (LDS)
 #define SEL_MAX_CELLS 512
