@@ -38,7 +38,7 @@ BOUNDS = (0.0, 640.0, 0.0, 480.0)
 PNP = dict(probability=0.99, min_inliers=10, max_iterations=200, min_set=4, epsilon=0.28, th2=5.991)
 
 
-def make_cases(n_unique, seed0):
+def make_cases(n_unique, seed0, w=640, h=480):
     """n_unique two-view scenes with slightly different motions."""
     from sdslam_amd import synth
     rng = np.random.default_rng(seed0)
@@ -46,7 +46,7 @@ def make_cases(n_unique, seed0):
     for i in range(n_unique):
         ups = np.array([0.02, -0.01, 0.015]) + rng.normal(size=3) * 0.004
         om = np.array([0.4, -0.3, 0.5]) + rng.normal(size=3) * 0.1
-        scenes.append(synth.make_scene(seed0 + i, tuple(ups), tuple(om)))
+        scenes.append(synth.make_scene(seed0 + i, tuple(ups), tuple(om), w, h))
     return scenes
 
 
@@ -145,10 +145,14 @@ def main():
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic scenes (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--orb-only", action="store_true", help="time ORB extraction alone (configs[1] without tracking)")
+    ap.add_argument("--res", default="640x480", help="frame size WxH (BASELINE configs[4] uses 1280x720 frames; the metric is quoted at 640x480)")
     ap.add_argument("--pose-solver", choices=["pnp", "poseopt"], default="pnp",
                     help="pnp: PnPsolver RANSAC (the BASELINE metric); poseopt: Optimizer::PoseOptimization, the pose solve the reference's "
                          "TrackWithMotionModel really calls (SURVEY D1) -- reported under the same metric name with config.pose_solver set")
     args = ap.parse_args()
+    global W, H, BOUNDS
+    W, H = (int(v) for v in args.res.lower().split("x"))
+    BOUNDS = (0.0, float(W), 0.0, float(H))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -169,7 +173,7 @@ def main():
     B = args.batch
     K = (synth.FX, synth.FY, synth.CX, synth.CY)
     nu = max(1, min(args.unique, B))
-    scenes = make_cases(nu, 1000 + 100 * rank)
+    scenes = make_cases(nu, 1000 + 100 * rank, W, H)
     idx = [i % nu for i in range(B)]
     cur_frames = np.stack([scenes[i]["cur"] for i in idx])
     ref_frames = np.stack([scenes[i]["ref"] for i in idx])
@@ -263,8 +267,8 @@ def main():
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("ORB extract only (BASELINE configs[1] without matching)" if args.orb_only else
-                                    "BASELINE configs[3] at the configs[1] pyramid: 640x480, 8-level x1.2, 1000 kp; "
+            "config": {"workload": (f"ORB extract only (BASELINE configs[1] without matching), {W}x{H}" if args.orb_only else
+                                    f"BASELINE configs[3] at the configs[1] pyramid: {W}x{H}, 8-level x1.2, 1000 kp; "
                                     "ORB extract + ImageAlign (levels 4,3,2) + SearchByProjection + " +
                                     ("PnP RANSAC 200 its" if args.pose_solver == "pnp" else "Optimizer::PoseOptimization (g2o LM, 4x10 its)")),
                        "pose_solver": args.pose_solver,
