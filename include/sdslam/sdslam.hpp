@@ -144,6 +144,8 @@ class TrackBatch {
   }
   // LastFrame.GetPose(), CurrentFrame.GetPose() (prior); 16 doubles column-major each
   void SetPoses(int frame, const double* Tlast, const double* Tcur_prior) { check(sd_track_set_poses(h_, frame, 1, Tlast, Tcur_prior)); }
+  // one current frame (frame `cur_frame` of the cur extractor) against the keyframes held in the batch slots; -1 = off
+  void SetCurrentBroadcast(int cur_frame) { check(sd_track_set_current_broadcast(h_, cur_frame)); }
   // Frame::ComputeStereoFromRGBD (src/Frame.cc:399-417) on the current frames: depth = CV_32F images, one per frame
   void ComputeStereoFromRGBD(int n_frames, const float* imDepth, int cols, int rows, int step_elems, size_t frame_step_elems) {
     check(sd_track_stereo_from_depth(h_, n_frames, imDepth, cols, rows, step_elems, frame_step_elems));
@@ -235,6 +237,34 @@ class Optimizer {
     int32_t info[8];
     check(sd_track_get_pose_opt(batch.handle(), frame, 1, Tcw, mvbOutlier.data(), kp_cap, info));
     return info[5];
+  }
+};
+
+// Tracking::Relocalization (src/Tracking.cc:1064-1097): every keyframe attempt of the loop is one slot of `batch`
+// (slot order = the order the reference tries them, kfs.rbegin() first; SetLastFrame = the keyframe's map points,
+// SetPoses(kf pose, kf pose)).  Returns the slot at which the reference's loop returns true, or -1.
+class Tracking {
+ public:
+  static int Relocalization(TrackBatch& batch, int n_keyframes, int cur_frame, float threshold, bool bMono) {
+    int32_t winner = -1;
+    check(sd_track_relocalize(batch.handle(), n_keyframes, cur_frame, threshold, bMono ? 1 : 0, 20, 10, &winner, nullptr));
+    return winner;
+  }
+};
+
+// The candidate search of LoopClosing::DetectLoop (src/LoopClosing.cc:115-149): slot i = kfs[i]; excluded[i] marks the
+// current keyframe itself and its connected keyframes.  Returns the slots with error < 1.5 * best (vpCandidateKFs as a set).
+class LoopClosing {
+ public:
+  static std::vector<int32_t> DetectLoopCandidates(TrackBatch& batch, int n_keyframes, int cur_frame, const std::vector<uint8_t>& excluded,
+                                                   double* best_error = nullptr) {
+    if (!excluded.empty() && (int)excluded.size() < n_keyframes) throw Error(SD_ERR_INVALID_ARG, "excluded shorter than n_keyframes");
+    std::vector<int32_t> cand(n_keyframes);
+    int32_t n = 0;
+    check(sd_track_detect_loop(batch.handle(), n_keyframes, cur_frame, excluded.empty() ? nullptr : excluded.data(), cand.data(),
+                               n_keyframes, &n, best_error, nullptr));
+    cand.resize(n);
+    return cand;
   }
 };
 

@@ -191,6 +191,27 @@ int sd_track_get_local(sd_track* h, int frame0, int n_frames, int32_t* local_mat
 int sd_track_pose_opt(sd_track* h, int n_frames, int source);
 int sd_track_get_pose_opt(sd_track* h, int frame0, int n_frames, double* Tcw_cm, uint8_t* outlier, int cap, int32_t* info8);
 
+/* One current frame against many keyframes.  After sd_track_set_current_broadcast(h, c) with c >= 0, slot f of every
+ * later sd_track_align / _match / _pnp / _pose_opt pairs its own map points, poses and ref-extractor frame f with frame c
+ * of the cur extractor (and with row c of mvuRight); -1 restores slot f <-> current frame f.  The cur extractor may then
+ * hold fewer frames than the tracker has slots.
+ *
+ * sd_track_relocalize: Tracking::Relocalization (src/Tracking.cc:1064-1097) with every keyframe attempt of its loop run
+ * as one batch slot: ImageAlign::ComputePose(frame, kf, fast) -> SearchByProjection(frame, kf, th, mono) with orientation
+ * check -> PoseOptimization.  Slots are in the order the reference tries them (newest keyframe first); *winner = first
+ * slot with align ok, nmatches >= min_matches (20) and nGood >= min_good (10), or -1 (= Relocalization returns false).
+ * stage3 (may be NULL): [n][3] = {align ok, nmatches, nGood} of every slot.
+ *
+ * sd_track_detect_loop: the candidate search of LoopClosing::DetectLoop (src/LoopClosing.cc:115-149):
+ * ImageAlign::ComputePose(mpCurrentKF, kfs[i]) for all i as one batch, then the reference's loop replayed over the
+ * results (skip excluded[i] != 0; a failed alignment also skips slot i+1; best error; keep error < 1.5 * best).
+ * candidates: slot indices in ascending order (the reference's std::map<KeyFrame*,...> order is pointer order). */
+int sd_track_set_current_broadcast(sd_track* h, int cur_frame);
+int sd_track_relocalize(sd_track* h, int n_keyframes, int cur_frame, float th, int mono, int min_matches, int min_good,
+                        int32_t* winner, int32_t* stage3);
+int sd_track_detect_loop(sd_track* h, int n_keyframes, int cur_frame, const uint8_t* excluded, int32_t* candidates, int cap,
+                         int32_t* n_candidates, double* best_error, double* errors);
+
 int sd_track_align(sd_track* h, int n_frames, int mode);
 int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori);
 int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers, int max_iterations,

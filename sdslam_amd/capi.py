@@ -460,6 +460,32 @@ class Tracker:
         return dict(T=[_from_cm(t) for t in T], outlier=out.astype(bool), n_initial=info[:, 0], n_bad=info[:, 1], rounds=info[:, 2],
                     iterations=info[:, 3], lm_trials=info[:, 4], n_inliers=info[:, 5])
 
+    def set_current_broadcast(self, cur_frame):
+        """One current frame against many keyframes (-1: slot f <-> current frame f)."""
+        self.L.sd_track_set_current_broadcast.argtypes = [C.c_void_p, C.c_int]
+        _check(self.L.sd_track_set_current_broadcast(self.h, int(cur_frame)))
+
+    def relocalize(self, n_keyframes, cur_frame=0, th=15.0, mono=True, min_matches=20, min_good=10):
+        """Tracking::Relocalization (src/Tracking.cc:1064-1097), one batch slot per keyframe attempt."""
+        win = C.c_int32(-1)
+        st = np.zeros((n_keyframes, 3), np.int32)
+        self.L.sd_track_relocalize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _check(self.L.sd_track_relocalize(self.h, n_keyframes, cur_frame, th, int(mono), min_matches, min_good, C.byref(win), _p(st)))
+        return int(win.value), st
+
+    def detect_loop(self, n_keyframes, cur_frame=0, excluded=None):
+        """Candidate search of LoopClosing::DetectLoop (src/LoopClosing.cc:115-149)."""
+        ex = None if excluded is None else np.ascontiguousarray(excluded, np.uint8)
+        cand = np.zeros(n_keyframes, np.int32)
+        n = C.c_int32(0)
+        best = C.c_double(0)
+        err = np.zeros(n_keyframes)
+        self.L.sd_track_detect_loop.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p]
+        _check(self.L.sd_track_detect_loop(self.h, n_keyframes, cur_frame, None if ex is None else _p(ex), _p(cand), n_keyframes,
+                                           C.byref(n), C.byref(best), _p(err)))
+        return dict(candidates=cand[:n.value].copy(), best_error=best.value, errors=err)
+
     def align(self, n_frames, mode=0):
         _check(self.L.sd_track_align(self.h, n_frames, mode))
 

@@ -2,18 +2,25 @@
 //
 // Replaces SD_SLAM::ORBextractor (reference src/ORBextractor.cc).  Batched-frames-first:
 // every kernel takes the frame index as its outermost grid dimension, so one launch covers
-// all frames of a batch (and, for FAST / blur / descriptors, all pyramid levels).
+// all frames of a batch (and, for blur / selection / descriptors, all pyramid levels).
 //
-//   k_pyr_level      ComputePyramid                src/ORBextractor.cc:680-700 (resize + REFLECT_101 border, one pass)
+//   k_pyr_resize     ComputePyramid: resize        src/ORBextractor.cc:680-700 (interior pixels, table-driven bilinear)
+//   k_pyr_edges      ... copyMakeBorder columns    (left / right REFLECT_101 borders + unaligned interior remainder)
+//   k_pyr_rows       ... copyMakeBorder rows       (top / bottom border rows = copies of finished rows)
+//   k_pyr_level      same, single generic pass     (exact-2x INTER_AREA levels, byte-unaligned inputs, tiny levels)
 //   k_fast_cells     cv::FAST per grid cell        src/ORBextractor.cc:501-552 (FAST-9/16, score, cell-local 3x3 NMS)
-//   k_select_level   quota loop + retainBest       src/ORBextractor.cc:554-605 (libstdc++ introselect replay)
+//   k_select_level   quota loop + retainBest       src/ORBextractor.cc:554-605 (wave-parallel libstdc++ introselect replay)
 //   k_blur           GaussianBlur 7x7 s=2          src/ORBextractor.cc:659-660 (8-bit fixed point, separable)
 //   k_orient_desc    IC_Angle + steered rBRIEF     src/ORBextractor.cc:78-143, 608-618, 669-674
+//   k_undistort      Frame::UndistortKeyPoints     src/Frame.cc:335-366
 //
+// Streams per handle: main (resize chain, selection, descriptors), fast (FAST of a level as soon as the level is
+// complete), aux (blur); see launch_pipeline / pipeline_body and DESIGN.md section 5.
 // HBM layout (per frame): padded pyramid block (all levels, 19-px border, 64-B aligned rows),
 // blurred block (same geometry), candidate keys (u32: response<<24 | y<<12 | x, per cell, raster
 // order), selected keys per level, output keypoints (28 B) + descriptors (32 B).
-// Integer / byte work, HBM-bound: no MFMA anywhere (largest dense object is 7 taps).
+// Integer / byte work limited by VALU issue and load latency: no MFMA anywhere
+// (largest dense object is 7 taps).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -63,8 +63,10 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   SD_REQUIRE(cur && ref, SD_ERR_INVALID_ARG, "extractor handle is NULL");
   SD_REQUIRE(cur->device == ref->device && cur->nlevels == ref->nlevels && cur->scaleFactor == ref->scaleFactor,
              SD_ERR_INVALID_ARG, "cur/ref extractors must share device and pyramid parameters");
-  SD_REQUIRE(max_points >= 1 && max_points <= 2048 && max_batch >= 1 && max_batch <= cur->max_batch && max_batch <= ref->max_batch,
-             SD_ERR_INVALID_ARG, "bad capacities (max_points <= 2048, max_batch <= extractor max_batch)");
+  // `cur` may hold fewer frames than the tracker has slots: one current frame against many keyframes
+  // (sd_track_set_current_broadcast); slot-paired calls then check their n_frames against what `cur` extracted
+  SD_REQUIRE(max_points >= 1 && max_points <= 2048 && max_batch >= 1 && max_batch <= ref->max_batch, SD_ERR_INVALID_ARG,
+             "bad capacities (max_points <= 2048, max_batch <= the ref extractor's max_batch)");
   SD_REQUIRE(pnp_max_iterations >= 1 && pnp_max_iterations <= 4096, SD_ERR_INVALID_ARG, "bad pnp_max_iterations");
   int nsel = 0;
   for (int q : cur->hp.quota) nsel += q;
@@ -82,6 +84,7 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   TrackBuffers& tb = h->tb;
   tb.max_points = max_points;
   tb.kp_cap = nsel;
+  tb.cur_bcast = -1;
   int rc = SD_OK;
   auto A = [&](int r) { if (rc == SD_OK) rc = r; };
   A(dalloc(h, &tb.valid, B * M));
@@ -285,12 +288,25 @@ static int mark_reads(sd_track* h, bool used_ref) {
   return SD_OK;
 }
 
-static int check_ready(sd_track* h, int n_frames) {
+// per_cur_frame: the call walks the frames of `cur` themselves (not tracker slots), so the broadcast does not apply
+static int check_ready(sd_track* h, int n_frames, bool per_cur_frame = false) {
   SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
   SD_REQUIRE(h->have_cam, SD_ERR_INVALID_ARG, "sd_track_set_camera has not been called");
   SD_REQUIRE(n_frames >= 1 && n_frames <= h->max_batch, SD_ERR_CAPACITY, "n_frames exceeds max_batch");
-  SD_REQUIRE(h->cur->have_geom && h->cur->last_frames >= n_frames, SD_ERR_INVALID_ARG, "current frames have not been extracted");
+  const int need = (h->tb.cur_bcast >= 0 && !per_cur_frame) ? h->tb.cur_bcast + 1 : n_frames;
+  SD_REQUIRE(h->cur->have_geom && h->cur->last_frames >= need, SD_ERR_INVALID_ARG, "current frames have not been extracted");
   SD_HIP_CHECK(hipSetDevice(h->device));
+  return SD_OK;
+}
+
+// One current frame against n keyframes (Tracking::Relocalization, LoopClosing::DetectLoop): slot f of the tracker
+// (its map points, Tref/Tprior, the ref extractor's frame f) pairs with frame `cur_frame` of the cur extractor and with
+// that frame's mvuRight row.  -1 restores slot f <-> current frame f.
+int sd_track_set_current_broadcast(sd_track* h, int cur_frame) {
+  SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  SD_REQUIRE(cur_frame >= -1 && cur_frame < h->cur->max_batch && cur_frame < h->max_batch, SD_ERR_INVALID_ARG,
+             "cur_frame outside the cur extractor / tracker batch");
+  h->tb.cur_bcast = cur_frame;   // TrackBuffers travels by value with every launch: queued kernels keep the old setting
   return SD_OK;
 }
 
@@ -399,6 +415,87 @@ int sd_track_pose_opt(sd_track* h, int n_frames, int source) {
   return rc;
 }
 
+// Tracking::Relocalization (reference src/Tracking.cc:1064-1097) over all keyframes at once.  The reference walks the
+// keyframes newest first and, for each: sets the frame's pose to the keyframe's, ImageAlign::ComputePose(frame, kf, fast)
+// [continue on failure], clears mvpMapPoints, SearchByProjection(frame, kf, th, mono) [continue if < 20],
+// PoseOptimization [continue if nGood < 10], else returns true.  Nothing an attempt leaves behind is read by the next one
+// (pose and mvpMapPoints are reset, mvbOutlier is rewritten per edge), so the attempts are independent: slot i of the
+// tracker holds the i-th keyframe TRIED (caller order = kfs.rbegin() ...), all slots run the three stages against the
+// broadcast current frame, and the host returns the first slot that passes the three gates -- the keyframe at which the
+// sequential loop would have stopped.  Its pose / matches / outlier flags are slot `winner`'s (sd_track_get_pose_opt,
+// sd_track_get_matches).  Caller: sd_track_set_last (keyframe points), sd_track_set_poses(Tref = Tprior = kf pose).
+int sd_track_relocalize(sd_track* h, int n_keyframes, int cur_frame, float th, int mono, int min_matches, int min_good,
+                        int32_t* winner, int32_t* stage3 /* [n][3] align ok, nmatches, nGood; may be NULL */) {
+  SD_REQUIRE(h && winner, SD_ERR_INVALID_ARG, "NULL argument");
+  *winner = -1;
+  SD_REQUIRE(cur_frame >= 0, SD_ERR_INVALID_ARG, "cur_frame must name a frame of the cur extractor");
+  const int saved = h->tb.cur_bcast;
+  int rc = sd_track_set_current_broadcast(h, cur_frame);
+  if (rc != SD_OK) return rc;
+  rc = sd_track_align(h, n_keyframes, 2);
+  if (rc == SD_OK) rc = sd_track_match(h, n_keyframes, th, mono, 1);   // ORBmatcher matcher(0.75, true)
+  if (rc == SD_OK) rc = sd_track_pose_opt(h, n_keyframes, 0);
+  h->tb.cur_bcast = saved;
+  if (rc != SD_OK) return rc;
+  std::vector<int32_t> ok(n_keyframes), nm(n_keyframes), info((size_t)n_keyframes * 8);
+  hipStream_t s = h->pnp_stream;
+  SD_HIP_CHECK(hipMemcpyAsync(ok.data(), h->tb.al_ok, (size_t)n_keyframes * 4, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipMemcpyAsync(nm.data(), h->tb.n_matches, (size_t)n_keyframes * 4, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipMemcpyAsync(info.data(), h->tb.po_info, (size_t)n_keyframes * 32, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  for (int i = 0; i < n_keyframes; i++) {
+    const int good = info[(size_t)i * 8 + 5];
+    if (stage3) { stage3[i * 3] = ok[i]; stage3[i * 3 + 1] = nm[i]; stage3[i * 3 + 2] = good; }
+    if (*winner < 0 && ok[i] && nm[i] >= min_matches && good >= min_good) *winner = i;
+  }
+  return SD_OK;
+}
+
+// The candidate search of LoopClosing::DetectLoop (reference src/LoopClosing.cc:115-149): ImageAlign::ComputePose(
+// mpCurrentKF, kf) -- level 4 only, identity start, rejected above 0.03 -- against every keyframe of the map.  Slot i holds
+// kfs[i] (its GetMapPoints() in the caller's order, its pose as Tref, its pyramid in the ref extractor); the current
+// keyframe is frame `cur_frame` of the cur extractor.  excluded[i] != 0 marks the keyframes the loop `continue`s over before
+// aligning (the current keyframe itself, connected keyframes).  The reference's loop is replayed on the host over the batched
+// results, including its `i++` after a failed alignment (the keyframe after a failure is never looked at), then the
+// survivors with error < 1.5 * best are returned -- in slot order (the reference iterates a std::map<KeyFrame*, double>,
+// i.e. pointer order; only the SET is defined).
+int sd_track_detect_loop(sd_track* h, int n_keyframes, int cur_frame, const uint8_t* excluded, int32_t* candidates, int cap,
+                         int32_t* n_candidates, double* best_error, double* errors /* [n], 1e10 where rejected; may be NULL */) {
+  SD_REQUIRE(h && candidates && n_candidates && cap >= 0, SD_ERR_INVALID_ARG, "NULL argument");
+  *n_candidates = 0;
+  SD_REQUIRE(cur_frame >= 0, SD_ERR_INVALID_ARG, "cur_frame must name a frame of the cur extractor");
+  const int saved = h->tb.cur_bcast;
+  int rc = sd_track_set_current_broadcast(h, cur_frame);
+  if (rc != SD_OK) return rc;
+  rc = sd_track_align(h, n_keyframes, 3);
+  h->tb.cur_bcast = saved;
+  if (rc != SD_OK) return rc;
+  std::vector<int32_t> ok(n_keyframes);
+  std::vector<double> err(n_keyframes);
+  hipStream_t s = h->pnp_stream;
+  SD_HIP_CHECK(hipMemcpyAsync(ok.data(), h->tb.al_ok, (size_t)n_keyframes * 4, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipMemcpyAsync(err.data(), h->tb.al_err, (size_t)n_keyframes * 8, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  if (errors) std::memcpy(errors, err.data(), (size_t)n_keyframes * 8);
+  double best = 1e10;
+  std::vector<int32_t> kept;
+  for (int i = 0; i < n_keyframes; i++) {
+    if (excluded && excluded[i]) continue;
+    if (!ok[i]) { i++; continue; }   // "Skip some keyframes"
+    kept.push_back(i);
+    if (err[i] < best) best = err[i];
+  }
+  int n = 0;
+  for (int32_t i : kept)
+    if (err[i] < best * 1.5) {
+      SD_REQUIRE(n < cap, SD_ERR_CAPACITY, "candidates array too small");
+      candidates[n++] = i;
+    }
+  *n_candidates = n;
+  if (best_error) *best_error = best;
+  return SD_OK;
+}
+
 int sd_track_get_pose_opt(sd_track* h, int frame0, int n_frames, double* Tcw_cm, uint8_t* outlier, int cap, int32_t* info8) {
   TRACK_RANGE(h, frame0, n_frames);
   SD_REQUIRE(!outlier || cap >= h->kp_cap, SD_ERR_CAPACITY, "cap smaller than the keypoint capacity");
@@ -424,7 +521,7 @@ int sd_track_set_uright(sd_track* h, int frame0, int n_frames, const float* urig
 
 // Frame::ComputeStereoFromRGBD on the current frames of the batch: depth images (CV_32F, host memory)
 int sd_track_stereo_from_depth(sd_track* h, int n_frames, const float* depth, int w, int hgt, int stride_elems, size_t frame_stride_elems) {
-  int rc = check_ready(h, n_frames);
+  int rc = check_ready(h, n_frames, true);
   if (rc != SD_OK) return rc;
   SD_REQUIRE(depth && w >= 1 && hgt >= 1 && stride_elems >= w, SD_ERR_INVALID_ARG, "bad depth image");
   SD_HIP_CHECK(hipStreamSynchronize(h->pnp_stream));   // a queued match may still read the stereo arrays

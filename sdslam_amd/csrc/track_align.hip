@@ -276,7 +276,7 @@ __global__ __launch_bounds__(AL_THREADS, 4) void k_align(const OrbPlan* __restri
   for (int level = lvl_hi; level >= lvl_lo; level--) {
     const LevelGeom L = P->lv[level];
     const float scale = (mode == 3) ? (float)(1.0 / sf[level]) : inv_sf[level];
-    const uint8_t* img_cur = pyr_cur + (size_t)f * P->pyr_frame_bytes + L.off + (size_t)SD_EDGE * L.pstride + SD_EDGE;
+    const uint8_t* img_cur = pyr_cur + (size_t)(tb.cur_bcast >= 0 ? tb.cur_bcast : f) * P->pyr_frame_bytes + L.off + (size_t)SD_EDGE * L.pstride + SD_EDGE;
     const uint8_t* img_ref = pyr_ref + (size_t)f * P->pyr_frame_bytes + L.off + (size_t)SD_EDGE * L.pstride + SD_EDGE;
     const int cols = L.w, rows = L.h, step = L.pstride;
     const double fscale = cam.fx * scale;   // cam_fx_*scale

@@ -11,6 +11,8 @@ namespace sd {
 struct TrackBuffers {
   int max_points;        // capacity M of the last-frame arrays
   int kp_cap;            // keypoint capacity of the current frame (extractor's nsel)
+  int cur_bcast;         // >= 0: every batch slot pairs with THIS frame of the `cur` extractor (one current frame against
+                         // many keyframes: Relocalization, DetectLoop); -1: slot f pairs with current frame f
   // last frame (LastFrame.mvpMapPoints flattened; index i == last-frame keypoint index)
   uint8_t* valid;        // [B][M]   pMP != NULL && !mvbOutlier[i]
   double* Xw;            // [B][M][3] pMP->GetWorldPos()

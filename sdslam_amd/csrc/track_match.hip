@@ -191,9 +191,10 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = 64 * MT_WAVES;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int cap = tb.kp_cap;
-  const sd_keypoint* kps = kps_all + (size_t)f * cap;
-  const uint8_t* desc = desc_all + (size_t)f * cap * 32;
-  const int N = min(nkp_all[f], min(cap, KP2));
+  const int fc = tb.cur_bcast >= 0 ? tb.cur_bcast : f;   // current-frame slot (TrackBuffers::cur_bcast)
+  const sd_keypoint* kps = kps_all + (size_t)fc * cap;
+  const uint8_t* desc = desc_all + (size_t)fc * cap * 32;
+  const int N = min(nkp_all[fc], min(cap, KP2));
   MatchGeom G;
   G.th = th;
   G.invW = (float)GRID_COLS / (float)(cam.max_x - cam.min_x);   // mfGridElementWidthInv
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
   const float* l_ang = tb.angle + (size_t)f * M;
   const int32_t* l_obs = tb.obs + (size_t)f * M;
   const int n_last = min(tb.n_last[f], M);
-  const float* uright = tb.uright + (size_t)f * cap;
+  const float* uright = tb.uright + (size_t)fc * cap;
 
   // ---- AssignFeaturesToGrid: key = cell << 11 | index (PosInGrid uses round())
   for (int i = tid; i < KP2; i += NT) {
@@ -419,9 +420,10 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = 64 * MT_WAVES;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int cap = tb.kp_cap, M = MP;
-  const sd_keypoint* kps = kps_all + (size_t)f * cap;
-  const uint8_t* desc = desc_all + (size_t)f * cap * 32;
-  const int N = min(nkp_all[f], min(cap, KP2));
+  const int fc = tb.cur_bcast >= 0 ? tb.cur_bcast : f;   // current-frame slot (TrackBuffers::cur_bcast)
+  const sd_keypoint* kps = kps_all + (size_t)fc * cap;
+  const uint8_t* desc = desc_all + (size_t)fc * cap * 32;
+  const int N = min(nkp_all[fc], min(cap, KP2));
   const float invW = (float)GRID_COLS / (float)(cam.max_x - cam.min_x);
   const float invH = (float)GRID_ROWS / (float)(cam.max_y - cam.min_y);
   const int n_loc = min(tb.lm_n[f], M);
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
   const uint8_t* mp_desc = tb.lm_desc + (size_t)f * M * 32;
   const int32_t* l_obs = tb.lm_obs + (size_t)f * M;
   const uint8_t* kclaim = tb.lm_kclaim + (size_t)f * cap;
-  const float* uright = tb.uright + (size_t)f * cap;
+  const float* uright = tb.uright + (size_t)fc * cap;
   uint8_t* o_inview = tb.lm_inview + (size_t)f * M;
   float* o_proj = tb.lm_proj + (size_t)f * M * 3;
   int32_t* o_level = tb.lm_level + (size_t)f * M;

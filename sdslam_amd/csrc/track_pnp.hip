@@ -1031,8 +1031,9 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
   for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
   __syncthreads();
   const int cap = tb.kp_cap;
-  const sd_keypoint* kps = kps_all + (size_t)f * cap;
-  const int nkp = min(nkp_all[f], cap);   // mvpMapPointMatches.size()
+  const int fc = tb.cur_bcast >= 0 ? tb.cur_bcast : f;   // current-frame slot (TrackBuffers::cur_bcast)
+  const sd_keypoint* kps = kps_all + (size_t)fc * cap;
+  const int nkp = min(nkp_all[fc], cap);   // mvpMapPointMatches.size()
   const int32_t* cm = tb.cur_match + (size_t)f * cap;
   const double* Xw = tb.Xw + (size_t)f * tb.max_points * 3;
   int32_t* info = tb.pnp_info + (size_t)f * 8;

@@ -242,11 +242,12 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
   for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
     __syncthreads();
     const int cap = tb.kp_cap, M = tb.max_points;
-    const sd_keypoint* kps = kps_all + (size_t)f * cap;
-    const int nkp = min(nkp_all[f], cap);
+    const int fc = tb.cur_bcast >= 0 ? tb.cur_bcast : f;   // current-frame slot (TrackBuffers::cur_bcast)
+    const sd_keypoint* kps = kps_all + (size_t)fc * cap;
+    const int nkp = min(nkp_all[fc], cap);
     const int32_t* match = (source == 0 ? tb.cur_match : tb.lm_match) + (size_t)f * cap;
     const double* Xw_all = (source == 0 ? tb.Xw : tb.lm_Xw) + (size_t)f * M * 3;
-    const float* uright = tb.uright + (size_t)f * cap;
+    const float* uright = tb.uright + (size_t)fc * cap;
     uint8_t* outl = tb.po_outlier + (size_t)f * cap;
     double* T_out = tb.po_T + (size_t)f * 16;
     int32_t* info = tb.po_info + (size_t)f * 8;

@@ -126,6 +126,20 @@ def tracking_case(seed: int, ref_kps, ref_desc, max_points=300, **kw):
                 angle=ref_kps["angle"].astype(np.float32).copy(), obs=np.ones(n, np.int32))
 
 
+def keyframe_case(kps, desc, T_kf, max_points=300):
+    """Map points of a keyframe seen at pose T_kf (world = the scene's frame): the first `max_points` keypoints carry
+    the surface points they see.  Same dict as tracking_case (what Tracker.set_last takes)."""
+    n = len(kps)
+    R, t = T_kf[:3, :3], T_kf[:3, 3]
+    Ow = -R.T @ t
+    rays = np.stack([(kps["x"].astype(np.float64) - CX) / FX, (kps["y"].astype(np.float64) - CY) / FY, np.ones(n)], -1)
+    Xw = intersect_surface(Ow, rays @ R, 2.0) if n else np.zeros((0, 3))
+    valid = np.zeros(n, np.uint8)
+    valid[:min(n, max_points)] = 1
+    return dict(valid=valid, Xw=np.ascontiguousarray(Xw), desc=desc.copy(), octave=kps["octave"].astype(np.int32).copy(),
+                angle=kps["angle"].astype(np.float32).copy(), obs=np.ones(n, np.int32))
+
+
 def glibc_rand_stream(n, seed=1):
     """n raw rand() values of glibc's TYPE_3 additive-feedback generator seeded with `seed`.
     The reference never seeds: SD_SLAM::Random draws from the default seed-1 state (reference

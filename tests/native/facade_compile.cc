@@ -15,6 +15,11 @@ int main() {
   }
   SD_SLAM::PnPsolver p;
   p.SetRansacParameters(0.99, 10, 200, 4, 0.28f, 5.991f);
+  // instantiate the batched Relocalization / DetectLoop entry points (link check; they need a GPU to run)
+  auto reloc = &SD_SLAM::Tracking::Relocalization;
+  auto loop = &SD_SLAM::LoopClosing::DetectLoopCandidates;
+  auto popt = &SD_SLAM::Optimizer::PoseOptimization;
+  if (!reloc || !loop || !popt) return 4;
   std::printf("facade ok\n");
   return 0;
 }

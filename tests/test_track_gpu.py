@@ -425,6 +425,134 @@ def test_pose_optimization_matches_oracle(sd, oracle, rig):
     trk.set_last(0, [o["last"] for o in rig["oras"]])
 
 
+@pytest.fixture(scope="module")
+def kfmap(sd, oracle):
+    """One current frame and 8 keyframes of a small map: six see the current frame's scene from nearby or distant
+    poses, two show another place.  Slot order = the order the reference would try / list them."""
+    tex_a, tex_b = synth.make_image(71, 1280, 960), synth.make_image(72, 1280, 960)
+    T_cur = synth.se3_exp((0.015, -0.01, 0.01), (0.3, -0.2, 0.4))
+    kf_motion = [(tex_b, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)),                 # another place
+                 (tex_a, (0.30, -0.20, 0.10), (6.0, -5.0, 8.0)),            # same place, far away: alignment diverges
+                 (tex_a, (0.02, -0.005, 0.012), (0.35, -0.1, 0.3)),         # close
+                 (tex_b, (0.01, 0.0, 0.0), (0.1, 0.0, 0.0)),
+                 (tex_a, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)),                 # close
+                 (tex_a, (0.05, 0.03, -0.02), (1.0, 0.8, -0.9)),            # medium
+                 (tex_a, (0.012, -0.012, 0.008), (0.3, -0.25, 0.45)),       # closest
+                 (tex_a, (-0.04, 0.02, 0.03), (-0.7, 0.5, 0.2))]            # medium
+    NK = len(kf_motion)
+    T_kf = [synth.se3_exp(u, w) for _, u, w in kf_motion]
+    cur = sd.ORBextractor(*CFG, 640, 480, 1)
+    ref = sd.ORBextractor(*CFG, 640, 480, NK)
+    im_cur = synth.render_plane_view(tex_a, T_cur)
+    im_kf = np.stack([synth.render_plane_view(t, T) for (t, _, _), T in zip(kf_motion, T_kf)])
+    ck, cd, cn = cur.extract_batch(im_cur[None])
+    rk, rd, rn = ref.extract_batch(im_kf)
+    oc = oracle.OrbOracle(*CFG)
+    ock, ocd = oc.extract(im_cur)
+    assert np.array_equal(ock, ck[0, :cn[0]])
+    kfs = []
+    for i in range(NK):
+        orf = oracle.OrbOracle(*CFG)
+        ork, ord_ = orf.extract(im_kf[i])
+        assert np.array_equal(ork, rk[i, :rn[i]])
+        kfs.append(dict(orf=orf, last=synth.keyframe_case(ork, ord_, T_kf[i], max_points=400)))
+    trk = sd.Tracker(cur, ref, max_points=1000, max_batch=NK, pnp_max_iterations=300)   # cur holds ONE frame
+    trk.set_camera(*K, 0.0, BOUNDS)
+    trk.set_last(0, [k["last"] for k in kfs])
+    return dict(NK=NK, T_cur=T_cur, T_kf=T_kf, trk=trk, cur=cur, ref=ref, oc=oc, ck=ock, cd=ocd, kfs=kfs, tab=oc.tables())
+
+
+def test_relocalization_over_all_keyframes(sd, oracle, kfmap):
+    """Tracking::Relocalization (src/Tracking.cc:1064-1097) with every keyframe attempt as one batch slot against the
+    broadcast current frame: per slot the three stages equal the oracle's sequential ImageAlign(frame, kf, fast) ->
+    SearchByProjection -> PoseOptimization, and the winner is where the reference's loop stops."""
+    m, trk, NK = kfmap, kfmap["trk"], kfmap["NK"]
+    trk.set_poses(0, m["T_kf"], m["T_kf"])                  # mCurrentFrame.SetPose(kf->GetPose())
+    th = 15.0
+    winner, st = trk.relocalize(NK, cur_frame=0, th=th, mono=True)
+    ga, (cm, nm), gp = trk.get_align(0, NK), trk.get_matches(0, NK), trk.get_pose_opt(0, NK)
+    pc = [m["oc"].level(l) for l in range(8)]
+    n = len(m["ck"])
+    expect = -1
+    for i in range(NK):
+        k = m["kfs"][i]
+        pr = [k["orf"].level(l) for l in range(8)]
+        Xw = k["last"]["Xw"][k["last"]["valid"] != 0]
+        ra = oracle.align(pc, pr, m["tab"]["inv_sf"], m["tab"]["sf"], Xw, m["T_kf"][i], m["T_kf"][i], K, mode=2)
+        assert ga["ok"][i] == ra["ok"] == st[i, 0], i
+        T_al = ra["T"] if ra["ok"] else m["T_kf"][i]
+        assert np.abs(ga["T"][i] - T_al).max() <= POSE_TOL
+        # the later stages of every slot are checked from the DEVICE's aligned pose (a 1e-12 pose difference may flip a
+        # float comparison in the matcher; that sensitivity is the aligner's tolerance, not the matcher's)
+        nmo, ocm = oracle.search_by_projection(m["ck"], m["cd"], m["tab"]["sf"], BOUNDS, K, ga["T"][i], m["T_kf"][i], k["last"],
+                                               th=th, mono=True, check_ori=True)
+        assert nm[i] == nmo == st[i, 1] and np.array_equal(cm[i, :n], ocm), i
+        has = ocm >= 0
+        rp = oracle.pose_optimization(m["ck"], has, k["last"]["Xw"][np.maximum(ocm, 0)], m["tab"]["inv_sigma2"], K, ga["T"][i])
+        assert gp["n_inliers"][i] == rp["n_inliers"] == st[i, 2], i
+        assert np.array_equal(gp["outlier"][i, :n], rp["outlier"])
+        assert np.abs(gp["T"][i] - rp["T"]).max() <= POSE_TOL
+        if expect < 0 and ra["ok"] and nmo >= 20 and rp["n_inliers"] >= 10:
+            expect = i
+    assert winner == expect
+    assert winner == 2                                      # the wrong-place and too-far keyframes fail one of the gates
+    assert np.abs(gp["T"][winner][:3, 3] - m["T_cur"][:3, 3]).max() < 5e-3
+    # no keyframe of the right place -> Relocalization returns false
+    trk.set_last(0, [m["kfs"][0]["last"], m["kfs"][3]["last"]])
+    try:
+        # (slot 1 now pairs kf 3's points with kf 1's pyramid: garbage in, "no" out)
+        w2, st2 = trk.relocalize(2, cur_frame=0, th=th, mono=True)
+        assert w2 == -1
+    finally:
+        trk.set_last(0, [k["last"] for k in m["kfs"]])
+
+
+def test_detect_loop_candidates(sd, oracle, kfmap):
+    """LoopClosing::DetectLoop's candidate search (src/LoopClosing.cc:115-149): KF-KF ImageAlign of the current keyframe
+    against all keyframes in one launch, then the reference's loop (exclusions, skip-after-failure, 1.5 x best)."""
+    m, trk, NK = kfmap, kfmap["trk"], kfmap["NK"]
+    trk.set_poses(0, m["T_kf"], [np.eye(4)] * NK)
+    # level-4 KF-KF alignment rarely exceeds the 0.03 gate on this scene; the failure the loop meets in practice is a
+    # keyframe without map points ("No points to track!").  Slots 3 and 5 are such keyframes, so the reference's
+    # skip-after-failure hides slots 4 and 6 -- the closest keyframe -- unless an exclusion shifts the walk.
+    lasts = [dict(k["last"]) for k in m["kfs"]]
+    for i in (3, 5):
+        lasts[i]["valid"] = np.zeros_like(lasts[i]["valid"])
+    trk.set_last(0, lasts)
+    pc = [m["oc"].level(l) for l in range(8)]
+    ok, err = [], []
+    for i in range(NK):
+        pr = [m["kfs"][i]["orf"].level(l) for l in range(8)]
+        Xw = lasts[i]["Xw"][lasts[i]["valid"] != 0]
+        r = oracle.align(pc, pr, m["tab"]["inv_sf"], m["tab"]["sf"], Xw, m["T_kf"][i], np.eye(4), K, mode=3)
+        ok.append(r["ok"]); err.append(r["error"])
+
+    def reference_loop(excluded):
+        cand, best, i = {}, 1e10, 0
+        while i < NK:                           # for (i = 0; i < kfs.size(); i++)
+            if not excluded[i]:
+                if not ok[i]:
+                    i += 1                      # "Skip some keyframes"
+                else:
+                    cand[i] = err[i]
+                    best = min(best, err[i])
+            i += 1
+        return sorted(j for j, e in cand.items() if e < best * 1.5), best
+
+    for excluded in ([0] * NK, [0, 0, 1, 0, 0, 0, 1, 0], [1] * NK, [0, 1, 0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 1, 0, 0]):
+        g = trk.detect_loop(NK, cur_frame=0, excluded=excluded)
+        want, best = reference_loop(excluded)
+        assert list(g["candidates"]) == want, (excluded, g, want)
+        assert abs(g["best_error"] - best) <= 1e-7 * max(1.0, abs(best))
+        for i in range(NK):
+            assert abs(g["errors"][i] - err[i]) <= 1e-7 * max(1.0, abs(err[i]))
+    assert sum(ok) >= 3 and not all(ok)
+    g = trk.detect_loop(NK, cur_frame=0, excluded=None)
+    assert list(g["candidates"]) == reference_loop([0] * NK)[0] and 6 not in g["candidates"]
+    assert 6 in trk.detect_loop(NK, cur_frame=0, excluded=[0, 0, 0, 1, 0, 1, 0, 0])["candidates"]
+    trk.set_last(0, [k["last"] for k in m["kfs"]])
+
+
 def test_degenerate_frames_through_the_whole_chain(sd, oracle):
     """A textureless current frame (0 keypoints), an empty last frame and an empty local map go through every stage
     without faults and give the reference's 'nothing to do' outcomes; a partial batch (n < max_batch) works."""
