@@ -73,6 +73,14 @@ def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0, pose_solver="pnp"):
         tb = time.perf_counter()
         pc = [cur.level(l) for l in range(CFG[2])]
         tb2 = time.perf_counter()
+        if pose_solver == "motion_model":      # the reference function as a whole (oracle composition of the same stages)
+            O.track_with_motion_model(pc, ref_pyr[i], tab, ck, cd, BOUNDS, K, s["T_ref"], T0s[i], last, 8.0, mono=True)
+            te = time.perf_counter()
+            t_stage += [tb - ta, te - tb2, 0.0, 0.0]
+            n += 1
+            if time.perf_counter() - t0 > budget_s or n >= 1000:
+                break
+            continue
         r = O.align(pc, ref_pyr[i], tab["inv_sf"], tab["sf"], last["Xw"][last["valid"] != 0], s["T_ref"], T0s[i], K, 0)
         tc = time.perf_counter()
         nm, cm = O.search_by_projection(ck, cd, tab["sf"], BOUNDS, K, r["T"], s["T_ref"], last, th=8.0)
@@ -94,7 +102,8 @@ def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0, pose_solver="pnp"):
     dt = t_stage.sum()      # excludes the Python-side pyramid copies between the C calls
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n} VGA frame pairs, full step (ORB extract + ImageAlign + SearchByProjection + "
-                      f"{'PnP RANSAC' if pose_solver == 'pnp' else 'PoseOptimization'}), "
+                      f"{'PnP RANSAC' if pose_solver == 'pnp' else 'PoseOptimization'}"
+                      f"{', composed as Tracking::TrackWithMotionModel (align+match+pose under image_align)' if pose_solver == 'motion_model' else ''}), "
                       f"1 thread of {os.cpu_count()} host cpus",
             "ms_per_frame": {"orb_extract": t_stage[0] / n * 1e3, "image_align": t_stage[1] / n * 1e3,
                              "search_by_projection": t_stage[2] / n * 1e3, "pose_solve": t_stage[3] / n * 1e3}}
@@ -146,9 +155,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--orb-only", action="store_true", help="time ORB extraction alone (configs[1] without tracking)")
     ap.add_argument("--res", default="640x480", help="frame size WxH (BASELINE configs[4] uses 1280x720 frames; the metric is quoted at 640x480)")
-    ap.add_argument("--pose-solver", choices=["pnp", "poseopt"], default="pnp",
+    ap.add_argument("--pose-solver", choices=["pnp", "poseopt", "motion_model"], default="pnp",
                     help="pnp: PnPsolver RANSAC (the BASELINE metric); poseopt: Optimizer::PoseOptimization, the pose solve the reference's "
-                         "TrackWithMotionModel really calls (SURVEY D1) -- reported under the same metric name with config.pose_solver set")
+                         "TrackWithMotionModel really calls (SURVEY D1) -- reported under the same metric name with config.pose_solver set; "
+                         "motion_model: the whole Tracking::TrackWithMotionModel as one call (retry search, failure exits, outlier discard)")
     args = ap.parse_args()
     global W, H, BOUNDS
     W, H = (int(v) for v in args.res.lower().split("x"))
@@ -198,7 +208,9 @@ def main():
 
     def step():
         cur.extract_batch_device(d_cur.ptr, B, W, H)
-        if not args.orb_only:
+        if not args.orb_only and args.pose_solver == "motion_model":
+            trk.track_with_motion_model(B, th=8.0, mono=True, align_mode=0)
+        elif not args.orb_only:
             trk.align(B, 0)
             trk.match(B, 8.0, True, True)
             if args.pose_solver == "pnp":
@@ -234,6 +246,9 @@ def main():
     al = trk.get_align(0, B)
     if args.pose_solver == "pnp" or args.orb_only:
         pn = trk.get_pnp(0, B)
+    elif args.pose_solver == "motion_model":
+        po, tw = trk.get_pose_opt(0, B), trk.get_tracked(0, B)
+        pn = dict(ok=tw["status"] == 2, n_inliers=tw["nmatches_map"], iterations=po["iterations"], N=po["n_initial"])
     else:
         po = trk.get_pose_opt(0, B)
         pn = dict(ok=po["n_inliers"] >= 10, n_inliers=po["n_inliers"], iterations=po["iterations"], N=po["n_initial"])
@@ -270,7 +285,8 @@ def main():
             "config": {"workload": (f"ORB extract only (BASELINE configs[1] without matching), {W}x{H}" if args.orb_only else
                                     f"BASELINE configs[3] at the configs[1] pyramid: {W}x{H}, 8-level x1.2, 1000 kp; "
                                     "ORB extract + ImageAlign (levels 4,3,2) + SearchByProjection + " +
-                                    ("PnP RANSAC 200 its" if args.pose_solver == "pnp" else "Optimizer::PoseOptimization (g2o LM, 4x10 its)")),
+                                    ("PnP RANSAC 200 its" if args.pose_solver == "pnp" else "Optimizer::PoseOptimization (g2o LM, 4x10 its)") +
+                                    (", as one Tracking::TrackWithMotionModel call" if args.pose_solver == "motion_model" else "")),
                        "pose_solver": args.pose_solver,
                        "frames_per_gpu_per_step": B, "unique_scenes": nu, "inputs": "resident in HBM",
                        "pose_records": "all-gathered over RCCL" if world > 1 else "single GPU"},

@@ -245,6 +245,24 @@ class Optimizer {
 // SetPoses(kf pose, kf pose)).  Returns the slot at which the reference's loop returns true, or -1.
 class Tracking {
  public:
+  struct Tracked {
+    bool ok;            // return value of TrackWithMotionModel
+    int nmatches;       // after "Discard outliers"
+    int nmatchesMap;
+    bool retried;       // the 2 * threshold search ran
+  };
+  // Tracking::TrackWithMotionModel (src/Tracking.cc:654-718) for every frame of the batch; the caller has set the last
+  // frame (SetLastFrame) and the poses (SetPoses: last pose, motion-model prediction).  referenceKF: ImageAlign against
+  // the slot's keyframe as TrackReferenceKeyFrame does (:583-644); align_image = Tracking::align_image_ (:122).
+  static void TrackWithMotionModel(TrackBatch& batch, int n_frames, float threshold, bool bMono, bool align_image = true,
+                                   bool referenceKF = false) {
+    check(sd_track_with_motion_model(batch.handle(), n_frames, align_image ? (referenceKF ? 1 : 0) : -1, threshold, bMono ? 1 : 0, 20, 10));
+  }
+  static Tracked Result(TrackBatch& batch, int frame) {
+    int32_t i4[4];
+    check(sd_track_get_tracked(batch.handle(), frame, 1, i4));
+    return Tracked{i4[0] == 2, i4[1], i4[2], i4[3] != 0};
+  }
   static int Relocalization(TrackBatch& batch, int n_keyframes, int cur_frame, float threshold, bool bMono) {
     int32_t winner = -1;
     check(sd_track_relocalize(batch.handle(), n_keyframes, cur_frame, threshold, bMono ? 1 : 0, 20, 10, &winner, nullptr));

@@ -212,6 +212,17 @@ int sd_track_relocalize(sd_track* h, int n_keyframes, int cur_frame, float th, i
 int sd_track_detect_loop(sd_track* h, int n_keyframes, int cur_frame, const uint8_t* excluded, int32_t* candidates, int cap,
                          int32_t* n_candidates, double* best_error, double* errors);
 
+/* Tracking::TrackWithMotionModel (src/Tracking.cc:654-718) for the batch in one call: ImageAlign (align_mode 0: against the
+ * last frame; 1: ComputePose(frame, reference keyframe) as in TrackReferenceKeyFrame :583-644; -1: align_image_ off) ->
+ * SearchByProjection(th) -> if nmatches < min_matches: pose := predicted and SearchByProjection(2 th) -> if still
+ * < min_matches: failed -> PoseOptimization -> outliers discarded, nmatchesMap counted -> tracked iff nmatchesMap >=
+ * min_inliers.  The reference's constants are min_matches = 20, min_inliers = 10.  All per-frame decisions are taken on the
+ * device.  Afterwards: sd_track_get_tracked (info4 = status 0 few matches / 1 few inliers / 2 tracked, nmatches, nmatchesMap,
+ * retried), sd_track_get_pose_opt (the frame's pose; mvbOutlier all false after the discard), sd_track_get_matches
+ * (mvpMapPoints after the discard). */
+int sd_track_with_motion_model(sd_track* h, int n_frames, int align_mode, float th, int mono, int min_matches, int min_inliers);
+int sd_track_get_tracked(sd_track* h, int frame0, int n_frames, int32_t* info4);
+
 int sd_track_align(sd_track* h, int n_frames, int mode);
 int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori);
 int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers, int max_iterations,

@@ -430,3 +430,42 @@ def undistort_points(xy, K, dist5):
     L.orc_undistort_points.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     L.orc_undistort_points(len(xy), _p(xy), float(K[0]), float(K[1]), float(K[2]), float(K[3]), _p(d), _p(out))
     return out
+
+
+def track_with_motion_model(pyr_cur, pyr_ref, tab, kps_un, desc, bounds, K, T_last, T_pred, last, th, mono=True, align_mode=0,
+                            u_right=None, mbf=0.0, mb=0.0, min_matches=20, min_inliers=10, T_aligned=None):
+    """Tracking::TrackWithMotionModel (reference src/Tracking.cc:654-718) composed from the oracle's stages, decision by
+    decision: align (failure keeps the predicted pose, :668-672) -> SearchByProjection(th) (:676-678) -> < 20: pose :=
+    predicted, SearchByProjection(2 th) (:681-686) -> < 20: return false (:688-691) -> PoseOptimization (:694) -> discard
+    outliers, count nmatchesMap (:697-711) -> nmatchesMap >= 10 (:713-718).  align_mode 1 = TrackReferenceKeyFrame's
+    ComputePose(frame, keyframe) (:583-644); -1 = align_image_ off.  T_aligned (optional) replaces the aligner's pose by a
+    given one (tests pass the device's, so that the matcher is compared on identical input).
+    Returns dict(status 0 few matches / 1 few inliers / 2 tracked, nmatches, nmatches_map, retried, T, match[N], align)."""
+    ra = None
+    T = np.array(T_pred, np.float64)
+    if align_mode >= 0:
+        Xw = last["Xw"][np.asarray(last["valid"]) != 0]
+        ra = align(pyr_cur, pyr_ref, tab["inv_sf"], tab["sf"], Xw, T_last, T_pred, K, mode=align_mode)
+        if ra["ok"]:
+            T = ra["T"] if T_aligned is None else np.array(T_aligned, np.float64)
+    kw = dict(mono=mono, check_ori=True, u_right=u_right, mbf=mbf, mb=mb)
+    nm, cm = search_by_projection(kps_un, desc, tab["sf"], bounds, K, T, T_last, last, th=th, **kw)
+    retried = 0
+    if nm < min_matches:
+        T = np.array(T_pred, np.float64)
+        nm, cm = search_by_projection(kps_un, desc, tab["sf"], bounds, K, T, T_last, last, th=2 * th, **kw)
+        retried = 1
+    if nm < min_matches:
+        return dict(status=0, nmatches=nm, nmatches_map=0, retried=retried, T=T, match=cm, align=ra)
+    has = cm >= 0
+    rp = pose_optimization(kps_un, has, np.asarray(last["Xw"])[np.maximum(cm, 0)], tab["inv_sigma2"], K, T, u_right=u_right, bf=mbf)
+    cm = cm.copy()
+    nmap = 0
+    for i in range(len(cm)):
+        if cm[i] >= 0:
+            if rp["outlier"][i]:
+                cm[i] = -1
+                nm -= 1
+            elif last["obs"][cm[i]] > 0:
+                nmap += 1
+    return dict(status=2 if nmap >= min_inliers else 1, nmatches=nm, nmatches_map=nmap, retried=retried, T=rp["T"], match=cm, align=ra)

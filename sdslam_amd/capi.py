@@ -460,6 +460,18 @@ class Tracker:
         return dict(T=[_from_cm(t) for t in T], outlier=out.astype(bool), n_initial=info[:, 0], n_bad=info[:, 1], rounds=info[:, 2],
                     iterations=info[:, 3], lm_trials=info[:, 4], n_inliers=info[:, 5])
 
+    def track_with_motion_model(self, n_frames, th=15.0, mono=True, align_mode=0, min_matches=20, min_inliers=10):
+        """Tracking::TrackWithMotionModel (src/Tracking.cc:654-718) for the batch; align_mode 1 = against the reference
+        keyframe (TrackReferenceKeyFrame), -1 = align_image_ off."""
+        self.L.sd_track_with_motion_model.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        _check(self.L.sd_track_with_motion_model(self.h, n_frames, int(align_mode), th, int(mono), min_matches, min_inliers))
+
+    def get_tracked(self, frame0, n):
+        info = np.zeros((n, 4), np.int32)
+        self.L.sd_track_get_tracked.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _check(self.L.sd_track_get_tracked(self.h, frame0, n, _p(info)))
+        return dict(status=info[:, 0], nmatches=info[:, 1], nmatches_map=info[:, 2], retried=info[:, 3])
+
     def set_current_broadcast(self, cur_frame):
         """One current frame against many keyframes (-1: slot f <-> current frame f)."""
         self.L.sd_track_set_current_broadcast.argtypes = [C.c_void_p, C.c_int]

@@ -131,6 +131,7 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.po_T, B * 16));
   A(dalloc(h, &tb.po_outlier, B * K));
   A(dalloc(h, &tb.po_info, B * 8));
+  A(dalloc(h, &tb.tw_info, B * 4));
   A(dalloc(h, &h->d_inv_sigma2, (size_t)cur->nlevels));
   A(dalloc(h, &h->d_scale_thr, (size_t)SD_MAX_LEVELS));
   A(dalloc(h, &h->d_sf, (size_t)cur->nlevels));
@@ -413,6 +414,68 @@ int sd_track_pose_opt(sd_track* h, int n_frames, int source) {
   if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[5], s)); h->ev_calls[2]++; }
   if (rc == SD_OK) rc = mark_reads(h, false);
   return rc;
+}
+
+// Tracking::TrackWithMotionModel (reference src/Tracking.cc:654-718) / TrackReferenceKeyFrame (:583-644) for the batch, as
+// one queue of launches with the reference's per-frame decisions taken on the device (no host round trip):
+//   ImageAlign::ComputePose(cur, last)  [align_mode 0; 1 = (cur, reference keyframe); -1 = align_image_ off]; a failed
+//     alignment leaves the predicted pose
+//   SearchByProjection(cur, last, th, mono) with orientation check
+//   nmatches < min_matches (20): pose := predicted, SearchByProjection again with 2 * th       (k_match, retry_below)
+//   nmatches < min_matches: tracking failed (status 0), PoseOptimization is not run             (k_pose_opt gate)
+//   PoseOptimization; outliers lose their map point and flag; nmatchesMap = survivors with Observations() > 0;
+//   status 2 iff nmatchesMap >= min_inliers (10), else 1
+// The frame's pose (sd_track_get_pose_opt / the tracker's current pose), mvpMapPoints (sd_track_get_matches) and the
+// counts (sd_track_get_tracked) are what the reference leaves in mCurrentFrame.  TrackReferenceKeyFrame's second search
+// goes to mLastFrame, not to the keyframe (src/Tracking.cc:610): with align_mode 1 it equals the reference when the slot's
+// points serve both, otherwise run the stages separately.
+int sd_track_with_motion_model(sd_track* h, int n_frames, int align_mode, float th, int mono, int min_matches, int min_inliers) {
+  int rc = check_ready(h, n_frames);
+  if (rc != SD_OK) return rc;
+  SD_REQUIRE(align_mode >= -1 && align_mode <= 1, SD_ERR_INVALID_ARG, "align_mode must be -1 (off), 0 (last frame) or 1 (reference keyframe)");
+  SD_REQUIRE(min_matches >= 3 && min_inliers >= 0, SD_ERR_INVALID_ARG, "bad gates (reference: 20 matches, 10 inliers)");
+  hipStream_t s = h->pnp_stream;
+  const TrackBuffers& tb = h->tb;
+  const bool use_ref = align_mode >= 0;
+  if (use_ref)
+    SD_REQUIRE(h->ref->have_geom && h->ref->last_frames >= n_frames && h->ref->cur_w == h->cur->cur_w && h->ref->cur_h == h->cur->cur_h,
+               SD_ERR_INVALID_ARG, "reference frames not extracted or of different size");
+  rc = wait_inputs(h, use_ref, use_ref);
+  if (rc != SD_OK) return rc;
+  hipEvent_t* ev = h->ev[h->ev_calls[0] % sd_track::kRing];
+  hipEvent_t* ev1 = h->ev[h->ev_calls[1] % sd_track::kRing];
+  hipEvent_t* ev2 = h->ev[h->ev_calls[2] % sd_track::kRing];
+  SD_HIP_CHECK(hipMemsetAsync(tb.tw_info, 0, (size_t)n_frames * 16, s));
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[0], s));
+  if (use_ref) rc = launch_align(h->cur, h->ref, tb, h->cam, h->d_inv_sf, h->d_sf, n_frames, align_mode, s);
+  else SD_HIP_CHECK(hipMemcpyAsync(tb.Tcur, tb.Tprior, (size_t)n_frames * 128, hipMemcpyDeviceToDevice, s));
+  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[1], s)); h->ev_calls[0]++; }
+  if (rc != SD_OK) return rc;
+  if (use_ref) {
+    rc = mark_reads(h, true);
+    if (rc != SD_OK) return rc;
+    rc = wait_inputs(h, false);   // the matcher needs the keypoints, not only the pyramid
+    if (rc != SD_OK) return rc;
+  }
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev1[2], s));
+  rc = launch_match(h->cur, tb, h->cam, h->d_sf, n_frames, th, mono, 1, s);
+  if (rc == SD_OK) rc = launch_match(h->cur, tb, h->cam, h->d_sf, n_frames, 2.f * th, mono, 1, s, min_matches);
+  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev1[3], s)); h->ev_calls[1]++; }
+  if (rc != SD_OK) return rc;
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev2[4], s));
+  rc = launch_pose_opt(h->cur, tb, h->cam, h->d_inv_sigma2, 0, n_frames, s, min_matches, min_inliers);
+  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev2[5], s)); h->ev_calls[2]++; }
+  if (rc == SD_OK) rc = mark_reads(h, false);
+  return rc;
+}
+
+// info4 per frame: status (0 few matches, 1 few inliers, 2 tracked), nmatches after the discard, nmatchesMap, retried
+int sd_track_get_tracked(sd_track* h, int frame0, int n_frames, int32_t* info4) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(info4, SD_ERR_INVALID_ARG, "NULL argument");
+  SD_HIP_CHECK(hipMemcpyAsync(info4, h->tb.tw_info + (size_t)frame0 * 4, (size_t)n_frames * 16, hipMemcpyDeviceToHost, h->cur->stream));
+  SD_HIP_CHECK(hipStreamSynchronize(h->cur->stream));
+  return SD_OK;
 }
 
 // Tracking::Relocalization (reference src/Tracking.cc:1064-1097) over all keyframes at once.  The reference walks the

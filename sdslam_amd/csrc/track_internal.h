@@ -65,6 +65,9 @@ struct TrackBuffers {
   double* po_T;          // [B][16] optimised Tcw, column-major
   uint8_t* po_outlier;   // [B][kp_cap] mvbOutlier
   int32_t* po_info;      // [B][8]: nInitialCorrespondences, nBad, rounds, g2o iterations, LM trials, nInitial - nBad
+  // Tracking::TrackWithMotionModel outcome (sd_track_with_motion_model)
+  int32_t* tw_info;      // [B][4]: status (0 few matches, 1 few inliers, 2 tracked), nmatches after the outlier discard,
+                         //         nmatchesMap, 1 if the wider-window retry ran
 };
 
 struct TrackCam {
@@ -84,10 +87,12 @@ struct PnpParams {
 
 int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sf,
                  const float* d_sf, int n_frames, int mode, hipStream_t s);
+// retry_below > 0: only frames whose last search found fewer matches run, from the PRIOR pose (which becomes the frame's pose)
 int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, int n_frames, float th,
-                 int mono, int check_ori, hipStream_t s);
+                 int mono, int check_ori, hipStream_t s, int retry_below = 0);
+// min_matches > 0: the tail of Tracking::TrackWithMotionModel around PoseOptimization (gate, outlier discard, tw_info)
 int launch_pose_opt(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sigma2, int source, int n_frames,
-                    hipStream_t s);
+                    hipStream_t s, int min_matches = 0, int min_inliers = 0);
 int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, const float* d_scale_thr,
                        int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s);
 int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_depth, int w, int h,

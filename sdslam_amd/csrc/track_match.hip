@@ -174,8 +174,12 @@ __device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __rest
 //   i16 s_match[KP2] | u16 s_ev[KP2] | u16 s_cstart[64*48+2] | int s_hist[30] | int s_nlist
 __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
                                                           const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
-                                                          const float* __restrict__ sf, float th, int mono, int check_ori, int KP2) {
+                                                          const float* __restrict__ sf, float th, int mono, int check_ori, int KP2,
+                                                          int retry_below) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // "If few matches, ignores alignment and uses a wider window search" (src/Tracking.cc:684-689): the second search of
+  // TrackWithMotionModel runs only for the frames whose first search found < retry_below matches (whole-workgroup exit)
+  if (retry_below > 0 && tb.n_matches[blockIdx.x] >= retry_below) return;
   const int MP = tb.max_points;
   uint32_t* s_key = (uint32_t*)smem;
   uint32_t* s_list = s_key + KP2;
@@ -267,7 +271,10 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
     s_cstart[c] = (uint16_t)lo;
   }
   {
-    const double* Tc = tb.Tcur + (size_t)f * 16;   // column-major
+    // column-major; the retry searches from the predicted pose, which becomes the frame's pose (SetPose(predicted_pose))
+    const double* Tc = (retry_below > 0 ? tb.Tprior : tb.Tcur) + (size_t)f * 16;
+    if (retry_below > 0 && tid < 16) tb.Tcur[(size_t)f * 16 + tid] = Tc[tid];
+    if (retry_below > 0 && tid == 0) tb.tw_info[(size_t)f * 4 + 3] = 1;
     for (int r = 0; r < 3; r++) {
       for (int c = 0; c < 3; c++) G.R[r][c] = Tc[c * 4 + r];
       G.t[r] = Tc[12 + r];
@@ -689,7 +696,7 @@ int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam
 }
 
 int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, int n_frames, float th,
-                 int mono, int check_ori, hipStream_t s) {
+                 int mono, int check_ori, hipStream_t s, int retry_below) {
   int KP2 = 64;
   while (KP2 < tb.kp_cap) KP2 <<= 1;
   SD_REQUIRE(KP2 <= MT_MAXKP && tb.max_points <= 2048, SD_ERR_CAPACITY, "matcher supports at most 2048 keypoints / map points per frame");
@@ -697,7 +704,7 @@ int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam,
   const size_t lds = (size_t)KP2 * 4 + MT_LIST_CAP * 4 + (size_t)MP * 4 + (size_t)KP2 * 4 + (size_t)((MP + 31) >> 5) * 8 + (size_t)KP2 * 2 +
                      (size_t)KP2 * 2 + (GRID_COLS * GRID_ROWS + 2) * 2 + 4 + (HISTO_LENGTH + 1) * 4;
   hipLaunchKernelGGL(k_match, dim3(n_frames), dim3(64 * MT_WAVES), lds, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_desc,
-                     cur->d_nout, tb, cam, d_sf, th, mono, check_ori, KP2);
+                     cur->d_nout, tb, cam, d_sf, th, mono, check_ori, KP2, retry_below);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }

@@ -235,7 +235,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // source 0: map points of the frame-to-frame match (tb.cur_match -> tb.Xw); 1: of the local-map search (tb.lm_match -> tb.lm_Xw)
 __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all, TrackBuffers tb,
-                                                TrackCam tcam, const float* __restrict__ inv_sigma2, int source, int n_frames) {
+                                                TrackCam tcam, const float* __restrict__ inv_sigma2, int source, int n_frames,
+                                                int min_matches, int min_inliers) {
   __shared__ double s_A[36], s_b[6], s_x[8];
   __shared__ int s_ok;
   const int lane = threadIdx.x;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
     const int fc = tb.cur_bcast >= 0 ? tb.cur_bcast : f;   // current-frame slot (TrackBuffers::cur_bcast)
     const sd_keypoint* kps = kps_all + (size_t)fc * cap;
     const int nkp = min(nkp_all[fc], cap);
-    const int32_t* match = (source == 0 ? tb.cur_match : tb.lm_match) + (size_t)f * cap;
+    int32_t* match = (source == 0 ? tb.cur_match : tb.lm_match) + (size_t)f * cap;
     const double* Xw_all = (source == 0 ? tb.Xw : tb.lm_Xw) + (size_t)f * M * 3;
     const float* uright = tb.uright + (size_t)fc * cap;
     uint8_t* outl = tb.po_outlier + (size_t)f * cap;
@@ -267,6 +268,16 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
     if (lane == 0) {
       for (int k = 0; k < 8; k++) info[k] = 0;
       info[0] = nInitial;
+    }
+    // TrackWithMotionModel: "Not enough matches, tracking failed" returns before PoseOptimization (src/Tracking.cc:691-694)
+    const int nm_search = min_matches > 0 ? tb.n_matches[f] : 0;
+    if (min_matches > 0 && nm_search < min_matches) {
+      if (lane == 0) {
+        tb.tw_info[(size_t)f * 4 + 0] = 0;
+        tb.tw_info[(size_t)f * 4 + 1] = nm_search;
+        tb.tw_info[(size_t)f * 4 + 2] = 0;
+      }
+      continue;
     }
     if (nInitial < 3) continue;
     double R0[3][3], t0[3];
@@ -480,13 +491,41 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
       info[4] = trials_total;
       info[5] = nInitial - nBad;
     }
+    if (min_matches > 0) {
+      // "Discard outliers" (src/Tracking.cc:699-711): outliers lose their map point and their flag; the survivors whose
+      // point has observations count towards nmatchesMap.  The optimised pose is the frame's pose (pFrame->SetPose).
+      __syncthreads();   // T_out written by lane 0
+      const int32_t* obs = (source == 0 ? tb.obs : tb.lm_obs) + (size_t)f * M;
+      int nmatches = nm_search, nmap = 0;
+      for (int i0 = 0; i0 < nkp; i0 += 64) {
+        const int i = i0 + lane;
+        bool drop = false, inmap = false;
+        if (i < nkp && match[i] >= 0) {
+          if (outl[i]) {
+            drop = true;
+            match[i] = -1;
+            outl[i] = 0;
+          } else {
+            inmap = obs[match[i]] > 0;
+          }
+        }
+        nmatches -= __popcll(__ballot(drop));
+        nmap += __popcll(__ballot(inmap));
+      }
+      if (lane < 16) tb.Tcur[(size_t)f * 16 + lane] = T_out[lane];
+      if (lane == 0) {
+        tb.tw_info[(size_t)f * 4 + 0] = nmap >= min_inliers ? 2 : 1;
+        tb.tw_info[(size_t)f * 4 + 1] = nmatches;
+        tb.tw_info[(size_t)f * 4 + 2] = nmap;
+      }
+    }
   }
 }
 
 int launch_pose_opt(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sigma2, int source, int n_frames,
-                    hipStream_t s) {
+                    hipStream_t s, int min_matches, int min_inliers) {
   hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(64), 0, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam,
-                     d_inv_sigma2, source, n_frames);
+                     d_inv_sigma2, source, n_frames, min_matches, min_inliers);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }

@@ -19,7 +19,9 @@ int main() {
   auto reloc = &SD_SLAM::Tracking::Relocalization;
   auto loop = &SD_SLAM::LoopClosing::DetectLoopCandidates;
   auto popt = &SD_SLAM::Optimizer::PoseOptimization;
-  if (!reloc || !loop || !popt) return 4;
+  auto twmm = &SD_SLAM::Tracking::TrackWithMotionModel;
+  auto twres = &SD_SLAM::Tracking::Result;
+  if (!reloc || !loop || !popt || !twmm || !twres) return 4;
   std::printf("facade ok\n");
   return 0;
 }

@@ -425,6 +425,61 @@ def test_pose_optimization_matches_oracle(sd, oracle, rig):
     trk.set_last(0, [o["last"] for o in rig["oras"]])
 
 
+def test_track_with_motion_model_decisions(sd, oracle, rig):
+    """Tracking::TrackWithMotionModel as one call (src/Tracking.cc:654-718): the per-frame decisions taken on the device
+    (failed alignment keeps the prediction, wider-window retry from the prediction, the two failure exits, outlier discard,
+    nmatchesMap) equal the oracle's stage-by-stage composition; final pose within 1e-5, final mvpMapPoints identical."""
+    trk, B = rig["trk"], rig["B"]
+    scenes, oras = rig["scenes"], rig["oras"]
+    seen = set()
+    lasts = [dict(o["last"]) for o in oras]
+    lasts[3]["obs"] = np.where(np.arange(len(lasts[3]["obs"])) % 40 == 0, 1, 0).astype(np.int32)   # few points "in the map"
+    trk.set_last(0, lasts)
+    try:
+        cases = [  # (align_mode, th, prior perturbation per frame: translation scale, rotation scale)
+            (0, 15.0, [(1.0, 1.0)] * 4),
+            (1, 15.0, [(1.0, 1.0)] * 4),
+            (-1, 1.5, [(0.3, 0.3), (1.0, 1.0), (2.0, 2.0), (6.0, 6.0)]),
+            (-1, 0.6, [(0.5, 0.5), (1.5, 1.5), (3.0, 3.0), (0.2, 0.2)]),
+            (0, 2.0, [(40.0, 40.0), (1.0, 1.0), (25.0, 25.0), (1.0, 1.0)]),
+        ]
+        for align_mode, th, pert in cases:
+            T0 = [synth.se3_exp((0.004 * a, -0.003 * a, 0.002 * a), (0.05 * b, 0.03 * b, -0.04 * b)) @ s["T_cur"]
+                  for (a, b), s in zip(pert, scenes)]
+            trk.set_poses(0, [s["T_ref"] for s in scenes], T0)
+            T_al = None
+            if align_mode >= 0:      # the device's aligned poses (<= 1e-12 from the oracle's): the matcher is compared on these
+                trk.align(B, align_mode)
+                T_al = trk.get_align(0, B)["T"]
+                trk.set_poses(0, [s["T_ref"] for s in scenes], T0)
+            trk.track_with_motion_model(B, th=th, mono=True, align_mode=align_mode)
+            tw, gp, (cm, nm), ga = trk.get_tracked(0, B), trk.get_pose_opt(0, B), trk.get_matches(0, B), trk.get_align(0, B)
+            for i in range(B):
+                o = oras[i]
+                n = len(o["ck"])
+                pc = [o["oc"].level(l) for l in range(8)]
+                pr = [o["orf"].level(l) for l in range(8)]
+                T_dev_al = None if T_al is None else T_al[i]
+                r = oracle.track_with_motion_model(pc, pr, o["tab"], o["ck"], o["cd"], BOUNDS, K, scenes[i]["T_ref"], T0[i], lasts[i], th,
+                                                   mono=True, align_mode=align_mode, T_aligned=T_dev_al)
+                key = (align_mode, th, i)
+                assert tw["status"][i] == r["status"], (key, tw["status"][i], r["status"], tw["nmatches"][i], r["nmatches"])
+                assert tw["retried"][i] == r["retried"], key
+                assert tw["nmatches"][i] == r["nmatches"] and tw["nmatches_map"][i] == r["nmatches_map"], key
+                assert np.array_equal(cm[i, :n], r["match"]) and (cm[i, n:] == -1).all(), key
+                assert np.abs(gp["T"][i] - r["T"]).max() <= POSE_TOL, (key, np.abs(gp["T"][i] - r["T"]).max())
+                assert np.abs(ga["T"][i] - r["T"]).max() <= POSE_TOL          # the frame's pose IS the result
+                assert not gp["outlier"][i].any()                             # flags cleared by the discard
+                if r["status"] == 2 and th == 15.0:     # good prior, aligned: it also converges to the truth
+                    assert np.abs(gp["T"][i][:3, 3] - scenes[i]["T_cur"][:3, 3]).max() < 5e-3
+                seen.add((int(r["status"]), int(r["retried"])))
+    finally:
+        trk.set_last(0, [o["last"] for o in oras])
+    # every exit of the function was taken by some frame: tracked with / without retry, few matches after the retry,
+    # few inliers
+    assert {(2, 0), (2, 1), (0, 1)} <= seen and any(s == 1 for s, _ in seen), seen
+
+
 @pytest.fixture(scope="module")
 def kfmap(sd, oracle):
     """One current frame and 8 keyframes of a small map: six see the current frame's scene from nearby or distant
