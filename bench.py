@@ -50,7 +50,7 @@ def make_cases(n_unique, seed0, w=640, h=480):
     return scenes
 
 
-def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0, pose_solver="pnp"):
+def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0, pose_solver="pnp", locals_=None):
     """The oracle's full tracking step (-O3 -march=native build) on this host: 1 thread."""
     from oracle import oracle as O
     from sdslam_amd import synth
@@ -73,10 +73,13 @@ def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0, pose_solver="pnp"):
         tb = time.perf_counter()
         pc = [cur.level(l) for l in range(CFG[2])]
         tb2 = time.perf_counter()
-        if pose_solver == "motion_model":      # the reference function as a whole (oracle composition of the same stages)
-            O.track_with_motion_model(pc, ref_pyr[i], tab, ck, cd, BOUNDS, K, s["T_ref"], T0s[i], last, 8.0, mono=True)
+        if pose_solver in ("motion_model", "track"):      # the reference functions as a whole (oracle composition of the same stages)
+            r = O.track_with_motion_model(pc, ref_pyr[i], tab, ck, cd, BOUNDS, K, s["T_ref"], T0s[i], last, 8.0, mono=True)
+            tl = time.perf_counter()
+            if pose_solver == "track":
+                O.track_local_map(ck, cd, tab, np.log(np.float32(CFG[1])), BOUNDS, K, r["T"], r["match"], last, locals_[i], th=1.0)
             te = time.perf_counter()
-            t_stage += [tb - ta, te - tb2, 0.0, 0.0]
+            t_stage += [tb - ta, tl - tb2, te - tl, 0.0]
             n += 1
             if time.perf_counter() - t0 > budget_s or n >= 1000:
                 break
@@ -103,7 +106,8 @@ def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0, pose_solver="pnp"):
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n} VGA frame pairs, full step (ORB extract + ImageAlign + SearchByProjection + "
                       f"{'PnP RANSAC' if pose_solver == 'pnp' else 'PoseOptimization'}"
-                      f"{', composed as Tracking::TrackWithMotionModel (align+match+pose under image_align)' if pose_solver == 'motion_model' else ''}), "
+                      f"{', composed as Tracking::TrackWithMotionModel (align+match+pose under image_align)' if pose_solver in ('motion_model', 'track') else ''}"
+                      f"{' + Tracking::TrackLocalMap (under search_by_projection)' if pose_solver == 'track' else ''}), "
                       f"1 thread of {os.cpu_count()} host cpus",
             "ms_per_frame": {"orb_extract": t_stage[0] / n * 1e3, "image_align": t_stage[1] / n * 1e3,
                              "search_by_projection": t_stage[2] / n * 1e3, "pose_solve": t_stage[3] / n * 1e3}}
@@ -155,10 +159,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--orb-only", action="store_true", help="time ORB extraction alone (configs[1] without tracking)")
     ap.add_argument("--res", default="640x480", help="frame size WxH (BASELINE configs[4] uses 1280x720 frames; the metric is quoted at 640x480)")
-    ap.add_argument("--pose-solver", choices=["pnp", "poseopt", "motion_model"], default="pnp",
+    ap.add_argument("--pose-solver", choices=["pnp", "poseopt", "motion_model", "track"], default="pnp",
                     help="pnp: PnPsolver RANSAC (the BASELINE metric); poseopt: Optimizer::PoseOptimization, the pose solve the reference's "
                          "TrackWithMotionModel really calls (SURVEY D1) -- reported under the same metric name with config.pose_solver set; "
-                         "motion_model: the whole Tracking::TrackWithMotionModel as one call (retry search, failure exits, outlier discard)")
+                         "motion_model: the whole Tracking::TrackWithMotionModel as one call (retry search, failure exits, outlier discard); "
+                         "track: motion_model followed by Tracking::TrackLocalMap over a ~1000-point local map per frame")
     args = ap.parse_args()
     global W, H, BOUNDS
     W, H = (int(v) for v in args.res.lower().split("x"))
@@ -208,8 +213,10 @@ def main():
 
     def step():
         cur.extract_batch_device(d_cur.ptr, B, W, H)
-        if not args.orb_only and args.pose_solver == "motion_model":
+        if not args.orb_only and args.pose_solver in ("motion_model", "track"):
             trk.track_with_motion_model(B, th=8.0, mono=True, align_mode=0)
+            if args.pose_solver == "track":
+                trk.track_local_map(B, th=1.0)
         elif not args.orb_only:
             trk.align(B, 0)
             trk.match(B, 8.0, True, True)
@@ -226,6 +233,12 @@ def main():
         torch.cuda.synchronize()
 
     trk.set_poses(0, T_ref, T0)         # last-frame poses + motion-model predictions (resident, like the frames)
+    locals_u = None
+    if args.pose_solver == "track" and not args.orb_only:      # the local map of every frame (UpdateLocalMap is the caller's)
+        ck, cd, cn = cur.extract_batch(np.stack([s_["cur"] for s_ in scenes]))
+        locals_u = [{k: v[:1000] for k, v in synth.local_map_case(500 + i, ck[i, :cn[i]], cd[i, :cn[i]], scenes[i]["T_cur"]).items()}
+                    for i in range(nu)]
+        trk.set_local(0, [locals_u[i] for i in idx])
     for _ in range(args.warmup):
         step()
     cur.sync()
@@ -239,6 +252,8 @@ def main():
     dt = time.perf_counter() - t0
     orb_ms = cur.stage_ms()
     trk_ms = trk.stage_ms() if not args.orb_only else np.zeros(3, np.float32)
+    if args.pose_solver == "track" and not args.orb_only:
+        trk_ms[1:] *= 2      # the timers average per call; search and PoseOptimization run twice per step here
     cur.set_profiling(False)
     trk.set_profiling(False)
 
@@ -249,6 +264,9 @@ def main():
     elif args.pose_solver == "motion_model":
         po, tw = trk.get_pose_opt(0, B), trk.get_tracked(0, B)
         pn = dict(ok=tw["status"] == 2, n_inliers=tw["nmatches_map"], iterations=po["iterations"], N=po["n_initial"])
+    elif args.pose_solver == "track":
+        po, tl = trk.get_pose_opt(0, B), trk.get_local_map(0, B)
+        pn = dict(ok=tl["status"] == 2, n_inliers=tl["n_inliers"], iterations=po["iterations"], N=po["n_initial"])
     else:
         po = trk.get_pose_opt(0, B)
         pn = dict(ok=po["n_inliers"] >= 10, n_inliers=po["n_inliers"], iterations=po["iterations"], N=po["n_initial"])
@@ -286,7 +304,8 @@ def main():
                                     f"BASELINE configs[3] at the configs[1] pyramid: {W}x{H}, 8-level x1.2, 1000 kp; "
                                     "ORB extract + ImageAlign (levels 4,3,2) + SearchByProjection + " +
                                     ("PnP RANSAC 200 its" if args.pose_solver == "pnp" else "Optimizer::PoseOptimization (g2o LM, 4x10 its)") +
-                                    (", as one Tracking::TrackWithMotionModel call" if args.pose_solver == "motion_model" else "")),
+                                    (", as one Tracking::TrackWithMotionModel call" if args.pose_solver in ("motion_model", "track") else "") +
+                                    (" + Tracking::TrackLocalMap (th 1, <=1000 local points)" if args.pose_solver == "track" else "")),
                        "pose_solver": args.pose_solver,
                        "frames_per_gpu_per_step": B, "unique_scenes": nu, "inputs": "resident in HBM",
                        "pose_records": "all-gathered over RCCL" if world > 1 else "single GPU"},
@@ -302,7 +321,7 @@ def main():
                          "mean_pnp_iterations": float(pn["iterations"].mean()), "align_translation_err_m": terr},
         }
         if not args.no_cpu_baseline and world == 1 and not args.orb_only:
-            line["cpu_baseline"] = cpu_baseline(scenes, lasts_u, T0_u, rs, pose_solver=args.pose_solver)
+            line["cpu_baseline"] = cpu_baseline(scenes, lasts_u, T0_u, rs, pose_solver=args.pose_solver, locals_=locals_u)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line, default=float))

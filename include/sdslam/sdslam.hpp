@@ -258,6 +258,19 @@ class Tracking {
                                    bool referenceKF = false) {
     check(sd_track_with_motion_model(batch.handle(), n_frames, align_image ? (referenceKF ? 1 : 0) : -1, threshold, bMono ? 1 : 0, 20, 10));
   }
+  // Tracking::TrackLocalMap (src/Tracking.cc:720-751) on top of TrackWithMotionModel's matches and pose; the local map is
+  // TrackBatch::SetLocalMap (UpdateLocalMap stays with the caller).  th: 1, 3 for RGB-D, 5 right after a relocalisation.
+  static void TrackLocalMap(TrackBatch& batch, int n_frames, float th = 1.f) { check(sd_track_local_map(batch.handle(), n_frames, th, 0.8f, 0.5f, 30)); }
+  // returns TrackLocalMap's return value; mnMatchesInliers and mvpMapPoints (v < max_points: last-frame point v, else
+  // local map point v - max_points) on request
+  static bool LocalMapResult(TrackBatch& batch, int frame, int* mnMatchesInliers = nullptr, std::vector<int32_t>* mvpMapPoints = nullptr,
+                             int kp_cap = 0) {
+    int32_t i4[4];
+    if (mvpMapPoints) mvpMapPoints->resize(kp_cap);
+    check(sd_track_get_local_map(batch.handle(), frame, 1, mvpMapPoints ? mvpMapPoints->data() : nullptr, kp_cap, i4));
+    if (mnMatchesInliers) *mnMatchesInliers = i4[2];
+    return i4[0] == 2;
+  }
   static Tracked Result(TrackBatch& batch, int frame) {
     int32_t i4[4];
     check(sd_track_get_tracked(batch.handle(), frame, 1, i4));

@@ -223,6 +223,18 @@ int sd_track_detect_loop(sd_track* h, int n_keyframes, int cur_frame, const uint
 int sd_track_with_motion_model(sd_track* h, int n_frames, int align_mode, float th, int mono, int min_matches, int min_inliers);
 int sd_track_get_tracked(sd_track* h, int frame0, int n_frames, int32_t* info4);
 
+/* Tracking::TrackLocalMap (src/Tracking.cc:720-751) for the batch, on top of the frame-to-frame matches and pose that
+ * sd_track_with_motion_model (or sd_track_match) left: SearchLocalPoints (:898-939) over the local map of sd_track_set_local
+ * (a keypoint is closed to the search where its frame match has Observations() > 0; kp_claimed of sd_track_set_local is not
+ * used) -> PoseOptimization over all of mvpMapPoints -> mnMatchesInliers -> tracked iff >= min_inliers (reference: 30).
+ * th = 1 (3 for RGB-D, 5 right after a relocalisation), nnratio = 0.8, viewing_cos_limit = 0.5 in the reference.
+ * sd_track_get_local_map: map_match[i] = -1 | v < max_points: last-frame point v | v >= max_points: local point v - max_points;
+ * info4 = {status 1 failed / 2 tracked, points in mvpMapPoints, mnMatchesInliers, local matches}.  Pose and mvbOutlier:
+ * sd_track_get_pose_opt; isInFrustum outputs: sd_track_get_local.  sd_track_pose_opt(h, n, 2) runs the optimisation alone
+ * on the same union. */
+int sd_track_local_map(sd_track* h, int n_frames, float th, float nnratio, float viewing_cos_limit, int min_inliers);
+int sd_track_get_local_map(sd_track* h, int frame0, int n_frames, int32_t* map_match, int cap, int32_t* info4);
+
 int sd_track_align(sd_track* h, int n_frames, int mode);
 int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori);
 int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers, int max_iterations,

@@ -469,3 +469,30 @@ def track_with_motion_model(pyr_cur, pyr_ref, tab, kps_un, desc, bounds, K, T_la
             elif last["obs"][cm[i]] > 0:
                 nmap += 1
     return dict(status=2 if nmap >= min_inliers else 1, nmatches=nm, nmatches_map=nmap, retried=retried, T=rp["T"], match=cm, align=ra)
+
+
+def track_local_map(kps_un, desc, tab, log_sf, bounds, K, T_cw, frame_match, last, local, th=1.0, nnratio=0.8, cos_limit=0.5,
+                    min_inliers=30, u_right=None, mbf=0.0):
+    """Tracking::TrackLocalMap (reference src/Tracking.cc:720-751) composed from the oracle's stages: SearchLocalPoints
+    (:898-939; keypoints whose frame match has observations are closed to the search, src/ORBmatcher.cc:81-83) ->
+    PoseOptimization over the union of frame matches and local matches (:729) -> mnMatchesInliers (:733-742) -> >= 30.
+    frame_match[N]: indices into `last` (-1 none); `local`: dict for search_local_points.  Returns dict(status 1 failed /
+    2 tracked, n_points, n_inliers, n_local, match[N] with local points as index + len(last arrays' capacity M), T, outlier, search)."""
+    frame_match = np.asarray(frame_match, np.int32)
+    N = len(kps_un)
+    claimed = np.array([frame_match[i] >= 0 and last["obs"][frame_match[i]] > 0 for i in range(N)], np.uint8)
+    sr = search_local_points(kps_un, desc, tab["sf"], log_sf, bounds, K, mbf, T_cw, local, th=th, nnratio=nnratio, cos_limit=cos_limit,
+                             u_right=u_right, kp_claimed=claimed)
+    lm = sr["match"]
+    has = (lm >= 0) | (frame_match >= 0)
+    Xw = np.zeros((N, 3))
+    obs = np.zeros(N, np.int64)
+    for i in range(N):
+        if lm[i] >= 0:
+            Xw[i], obs[i] = local["Xw"][lm[i]], local["obs"][lm[i]]
+        elif frame_match[i] >= 0:
+            Xw[i], obs[i] = last["Xw"][frame_match[i]], last["obs"][frame_match[i]]
+    rp = pose_optimization(kps_un, has, Xw, tab["inv_sigma2"], K, T_cw, u_right=u_right, bf=mbf)
+    ninl = int(sum(1 for i in range(N) if has[i] and not rp["outlier"][i] and obs[i] > 0))
+    return dict(status=2 if ninl >= min_inliers else 1, n_points=int(has.sum()), n_inliers=ninl, n_local=int((lm >= 0).sum()),
+                local_match=lm, frame_match=frame_match, has=has, T=rp["T"], outlier=rp["outlier"], search=sr)

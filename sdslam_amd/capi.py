@@ -472,6 +472,18 @@ class Tracker:
         _check(self.L.sd_track_get_tracked(self.h, frame0, n, _p(info)))
         return dict(status=info[:, 0], nmatches=info[:, 1], nmatches_map=info[:, 2], retried=info[:, 3])
 
+    def track_local_map(self, n_frames, th=1.0, nnratio=0.8, cos_limit=0.5, min_inliers=30):
+        """Tracking::TrackLocalMap (src/Tracking.cc:720-751) on top of the frame-to-frame matches and the current pose."""
+        self.L.sd_track_local_map.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
+        _check(self.L.sd_track_local_map(self.h, n_frames, th, nnratio, cos_limit, min_inliers))
+
+    def get_local_map(self, frame0, n):
+        mm = np.zeros((n, self.cap), np.int32)
+        info = np.zeros((n, 4), np.int32)
+        self.L.sd_track_get_local_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        _check(self.L.sd_track_get_local_map(self.h, frame0, n, _p(mm), self.cap, _p(info)))
+        return dict(match=mm, status=info[:, 0], n_points=info[:, 1], n_inliers=info[:, 2], n_local=info[:, 3])
+
     def set_current_broadcast(self, cur_frame):
         """One current frame against many keyframes (-1: slot f <-> current frame f)."""
         self.L.sd_track_set_current_broadcast.argtypes = [C.c_void_p, C.c_int]

@@ -132,6 +132,8 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.po_outlier, B * K));
   A(dalloc(h, &tb.po_info, B * 8));
   A(dalloc(h, &tb.tw_info, B * 4));
+  A(dalloc(h, &tb.un_match, B * K));
+  A(dalloc(h, &tb.tl_info, B * 4));
   A(dalloc(h, &h->d_inv_sigma2, (size_t)cur->nlevels));
   A(dalloc(h, &h->d_scale_thr, (size_t)SD_MAX_LEVELS));
   A(dalloc(h, &h->d_sf, (size_t)cur->nlevels));
@@ -404,7 +406,7 @@ int sd_track_get_local(sd_track* h, int frame0, int n_frames, int32_t* local_mat
 int sd_track_pose_opt(sd_track* h, int n_frames, int source) {
   int rc = check_ready(h, n_frames);
   if (rc != SD_OK) return rc;
-  SD_REQUIRE(source == 0 || source == 1, SD_ERR_INVALID_ARG, "source must be 0 (frame matches) or 1 (local-map matches)");
+  SD_REQUIRE(source >= 0 && source <= 2, SD_ERR_INVALID_ARG, "source must be 0 (frame matches), 1 (local-map matches) or 2 (both, as after SearchLocalPoints)");
   hipStream_t s = h->pnp_stream;
   rc = wait_inputs(h, false);
   if (rc != SD_OK) return rc;
@@ -467,6 +469,46 @@ int sd_track_with_motion_model(sd_track* h, int n_frames, int align_mode, float 
   if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev2[5], s)); h->ev_calls[2]++; }
   if (rc == SD_OK) rc = mark_reads(h, false);
   return rc;
+}
+
+// Tracking::TrackLocalMap (reference src/Tracking.cc:720-751) for the batch, after sd_track_with_motion_model (or any
+// sd_track_match) left the frame-to-frame matches and the pose: SearchLocalPoints (:898-939: isInFrustum + the local-map
+// SearchByProjection; a keypoint is closed to the search where its frame match has observations) -> PoseOptimization over
+// ALL of mvpMapPoints (frame matches and local matches) -> mnMatchesInliers -> tracked iff >= min_inliers (30).
+// The local map (sd_track_set_local) is the caller's UpdateLocalMap(); its `cand` flags carry the "already matched in this
+// frame / isBad" skips of :916-921, kp_claimed is ignored here.  th: 1, 3 for RGB-D, 5 after a relocalisation (:929-934).
+int sd_track_local_map(sd_track* h, int n_frames, float th, float nnratio, float viewing_cos_limit, int min_inliers) {
+  int rc = check_ready(h, n_frames);
+  if (rc != SD_OK) return rc;
+  SD_REQUIRE(min_inliers >= 0, SD_ERR_INVALID_ARG, "bad min_inliers (reference: 30)");
+  hipStream_t s = h->pnp_stream;
+  rc = wait_inputs(h, false);
+  if (rc != SD_OK) return rc;
+  hipEvent_t* ev1 = h->ev[h->ev_calls[1] % sd_track::kRing];
+  hipEvent_t* ev2 = h->ev[h->ev_calls[2] % sd_track::kRing];
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev1[2], s));
+  rc = launch_match_local(h->cur, h->tb, h->cam, h->d_sf, h->d_scale_thr, h->cur->nlevels, n_frames, th, nnratio, viewing_cos_limit, s, 1);
+  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev1[3], s)); h->ev_calls[1]++; }
+  if (rc != SD_OK) return rc;
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev2[4], s));
+  rc = launch_pose_opt(h->cur, h->tb, h->cam, h->d_inv_sigma2, 2, n_frames, s, 0, min_inliers);
+  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev2[5], s)); h->ev_calls[2]++; }
+  if (rc == SD_OK) rc = mark_reads(h, false);
+  return rc;
+}
+
+// map_match (may be NULL): mvpMapPoints after SearchLocalPoints, -1 | v < max_points: last-frame point v | v >= max_points:
+// local map point v - max_points.  info4: status (1 failed, 2 tracked), points in mvpMapPoints, mnMatchesInliers, local matches
+int sd_track_get_local_map(sd_track* h, int frame0, int n_frames, int32_t* map_match, int cap, int32_t* info4) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(!map_match || cap >= h->kp_cap, SD_ERR_CAPACITY, "cap smaller than the keypoint capacity");
+  hipStream_t s = h->cur->stream;
+  if (map_match)
+    SD_HIP_CHECK(hipMemcpy2DAsync(map_match, (size_t)cap * 4, h->tb.un_match + (size_t)frame0 * h->kp_cap, (size_t)h->kp_cap * 4,
+                                  (size_t)h->kp_cap * 4, n_frames, hipMemcpyDeviceToHost, s));
+  if (info4) SD_HIP_CHECK(hipMemcpyAsync(info4, h->tb.tl_info + (size_t)frame0 * 4, (size_t)n_frames * 16, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
 }
 
 // info4 per frame: status (0 few matches, 1 few inliers, 2 tracked), nmatches after the discard, nmatchesMap, retried

@@ -68,6 +68,9 @@ struct TrackBuffers {
   // Tracking::TrackWithMotionModel outcome (sd_track_with_motion_model)
   int32_t* tw_info;      // [B][4]: status (0 few matches, 1 few inliers, 2 tracked), nmatches after the outlier discard,
                          //         nmatchesMap, 1 if the wider-window retry ran
+  // Tracking::TrackLocalMap (sd_track_local_map): mvpMapPoints after SearchLocalPoints = frame matches + local matches
+  int32_t* un_match;     // [B][kp_cap] -1 | v < M: last-frame point v | v >= M: local map point v - M
+  int32_t* tl_info;      // [B][4]: status (1 failed, 2 tracked), points in mvpMapPoints, mnMatchesInliers, local matches
 };
 
 struct TrackCam {
@@ -91,10 +94,13 @@ int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, c
 int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, int n_frames, float th,
                  int mono, int check_ori, hipStream_t s, int retry_below = 0);
 // min_matches > 0: the tail of Tracking::TrackWithMotionModel around PoseOptimization (gate, outlier discard, tw_info)
+// source 2 (+ min_inliers): TrackLocalMap -- the union of both match vectors, mnMatchesInliers, tl_info
 int launch_pose_opt(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sigma2, int source, int n_frames,
                     hipStream_t s, int min_matches = 0, int min_inliers = 0);
+// claim_from_matches: "keypoint already holds a point with Observations() > 0" is read off the frame-to-frame matches
+// (tb.cur_match / tb.obs) instead of the caller's lm_kclaim flags
 int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, const float* d_scale_thr,
-                       int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s);
+                       int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s, int claim_from_matches = 0);
 int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_depth, int w, int h,
                              int stride_elems, size_t frame_stride_elems, int n_frames, hipStream_t s);
 int read_pnp_prof(unsigned long long* out32, int reset);

@@ -412,7 +412,8 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
 __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
                                                                 const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
                                                                 const float* __restrict__ sf, const float* __restrict__ scale_thr,
-                                                                int nlevels, float th, float nnratio, float cos_limit, int KP2) {
+                                                                int nlevels, float th, float nnratio, float cos_limit, int KP2,
+                                                                int claim_from_matches) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int MP = tb.max_points;
   uint32_t* s_key = (uint32_t*)smem;
@@ -466,7 +467,16 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
   }
   for (int i0 = 0; i0 < KP2; i0 += NT) {   // claim flags / Observations() > 0 flags as bit masks (wave ballots)
     const int i = i0 + tid;
-    const unsigned long long bc = __ballot(i < N && kclaim[i] != 0);
+    bool claimed = false;
+    if (i < N) {
+      if (claim_from_matches) {   // F.mvpMapPoints[idx] && F.mvpMapPoints[idx]->Observations() > 0 (src/ORBmatcher.cc:81-83)
+        const int m = tb.cur_match[(size_t)f * cap + i];
+        claimed = m >= 0 && tb.obs[(size_t)f * MP + m] > 0;
+      } else {
+        claimed = kclaim[i] != 0;
+      }
+    }
+    const unsigned long long bc = __ballot(claimed);
     const int w = (i0 >> 5) + 2 * wave;
     if (lane == 0 && w < (KP2 >> 5)) {
       s_kclaim[w] = (uint32_t)bc;
@@ -682,7 +692,7 @@ int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const Tr
 }
 
 int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, const float* d_scale_thr,
-                       int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s) {
+                       int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s, int claim_from_matches) {
   int KP2 = 64;
   while (KP2 < tb.kp_cap) KP2 <<= 1;
   SD_REQUIRE(KP2 <= MT_MAXKP && tb.max_points <= 2048, SD_ERR_CAPACITY, "matcher supports at most 2048 keypoints / map points per frame");
@@ -690,7 +700,7 @@ int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam
   const size_t lds = (size_t)KP2 * 4 + MT_LIST_CAP * 4 + (size_t)MP * 4 + (size_t)((MP + 31) >> 5) * 4 + (size_t)(KP2 >> 5) * 4 + (size_t)KP2 * 2 +
                      (GRID_COLS * GRID_ROWS + 2) * 2 + (size_t)KP2 + 4 + 8;
   hipLaunchKernelGGL(k_match_local, dim3(n_frames), dim3(64 * MT_WAVES), lds, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_desc,
-                     cur->d_nout, tb, cam, d_sf, d_scale_thr, nlevels, th, nnratio, cos_limit, KP2);
+                     cur->d_nout, tb, cam, d_sf, d_scale_thr, nlevels, th, nnratio, cos_limit, KP2, claim_from_matches);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }

@@ -233,6 +233,33 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Tracking::TrackLocalMap after PoseOptimization (src/Tracking.cc:730-751): mnMatchesInliers = points of mvpMapPoints that
+// are not outliers and have observations; tracked iff >= min_inliers (30).  Nothing is discarded here.
+__device__ void tlm_tail(const TrackBuffers& tb, int f, int nkp, const int32_t* match, const uint8_t* outl, int nInitial, int min_inliers,
+                         int lane) {
+  const int M = tb.max_points;
+  const int32_t* obs_lo = tb.obs + (size_t)f * M;
+  const int32_t* obs_hi = tb.lm_obs + (size_t)f * M - M;
+  int ninl = 0, nloc = 0;
+  for (int i0 = 0; i0 < nkp; i0 += 64) {
+    const int i = i0 + lane;
+    bool inl = false, loc = false;
+    if (i < nkp && match[i] >= 0) {
+      const int m = match[i];
+      loc = m >= M;
+      inl = !outl[i] && (m >= M ? obs_hi : obs_lo)[m] > 0;
+    }
+    ninl += __popcll(__ballot(inl));
+    nloc += __popcll(__ballot(loc));
+  }
+  if (lane == 0) {
+    tb.tl_info[(size_t)f * 4 + 0] = ninl >= min_inliers ? 2 : 1;
+    tb.tl_info[(size_t)f * 4 + 1] = nInitial;
+    tb.tl_info[(size_t)f * 4 + 2] = ninl;
+    tb.tl_info[(size_t)f * 4 + 3] = nloc;
+  }
+}
+
 // source 0: map points of the frame-to-frame match (tb.cur_match -> tb.Xw); 1: of the local-map search (tb.lm_match -> tb.lm_Xw)
 __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all, TrackBuffers tb,
                                                 TrackCam tcam, const float* __restrict__ inv_sigma2, int source, int n_frames,
@@ -246,8 +273,11 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
     const int fc = tb.cur_bcast >= 0 ? tb.cur_bcast : f;   // current-frame slot (TrackBuffers::cur_bcast)
     const sd_keypoint* kps = kps_all + (size_t)fc * cap;
     const int nkp = min(nkp_all[fc], cap);
-    int32_t* match = (source == 0 ? tb.cur_match : tb.lm_match) + (size_t)f * cap;
-    const double* Xw_all = (source == 0 ? tb.Xw : tb.lm_Xw) + (size_t)f * M * 3;
+    int32_t* match = (source == 0 ? tb.cur_match : source == 1 ? tb.lm_match : tb.un_match) + (size_t)f * cap;
+    // source 2: indices >= M address the local-map arrays (XW below)
+    const double* Xw_lo = (source == 1 ? tb.lm_Xw : tb.Xw) + (size_t)f * M * 3;
+    const double* Xw_hi = tb.lm_Xw + (size_t)f * M * 3 - (size_t)M * 3;
+#define XW(m, k) (((m) >= M ? Xw_hi : Xw_lo)[(size_t)(m) * 3 + (k)])
     const float* uright = tb.uright + (size_t)fc * cap;
     uint8_t* outl = tb.po_outlier + (size_t)f * cap;
     double* T_out = tb.po_T + (size_t)f * 16;
@@ -257,6 +287,14 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
     const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);   // const float delta = sqrt(..)
     const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
 
+    if (source == 2) {
+      // mvpMapPoints after Tracking::SearchLocalPoints: a local match replaces whatever the keypoint held (it is only made
+      // where the keypoint held nothing or a point without observations, src/ORBmatcher.cc:81-83, :114)
+      const int32_t* fm = tb.cur_match + (size_t)f * cap;
+      const int32_t* lm = tb.lm_match + (size_t)f * cap;
+      for (int i = lane; i < cap; i += 64) match[i] = lm[i] >= 0 ? lm[i] + M : fm[i];
+      __syncthreads();
+    }
     int nInitial = 0;
     for (int i0 = 0; i0 < nkp; i0 += 64) {
       const int i = i0 + lane;
@@ -279,7 +317,13 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
       }
       continue;
     }
-    if (nInitial < 3) continue;
+    if (nInitial < 3) {
+      if (source == 2) {   // PoseOptimization returns 0 and leaves pose and flags alone; TrackLocalMap still counts
+        __syncthreads();
+        tlm_tail(tb, f, nkp, match, outl, nInitial, min_inliers, lane);
+      }
+      continue;
+    }
     double R0[3][3], t0[3];
     for (int r = 0; r < 3; r++) {
       for (int c = 0; c < 3; c++) R0[r][c] = T_in[c * 4 + r];
@@ -312,7 +356,7 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
           const float ur = uright[i];
           const bool stereo = !(ur < 0);
           const double infoe = (double)inv_sigma2[kp.octave];
-          const double Xw[3] = {Xw_all[(size_t)m * 3], Xw_all[(size_t)m * 3 + 1], Xw_all[(size_t)m * 3 + 2]};
+          const double Xw[3] = {XW(m, 0), XW(m, 1), XW(m, 2)};
           double e[3], p[3];
           const double c2 = po_error(est, Xw, kp.x, kp.y, ur, stereo, infoe, cam, e, p);
           double rho1 = 1.0;
@@ -408,7 +452,7 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
             const float ur = uright[i];
             const bool stereo = !(ur < 0);
             const double infoe = (double)inv_sigma2[kp.octave];
-            const double Xw[3] = {Xw_all[(size_t)m * 3], Xw_all[(size_t)m * 3 + 1], Xw_all[(size_t)m * 3 + 2]};
+            const double Xw[3] = {XW(m, 0), XW(m, 1), XW(m, 2)};
             double e[3], p[3];
             const double c2 = po_error(est, Xw, kp.x, kp.y, ur, stereo, infoe, cam, e, p);
             if (robust) {
@@ -459,7 +503,7 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
           const float ur = uright[i];
           const bool stereo = !(ur < 0);
           const double infoe = (double)inv_sigma2[kp.octave];
-          const double Xw[3] = {Xw_all[(size_t)m * 3], Xw_all[(size_t)m * 3 + 1], Xw_all[(size_t)m * 3 + 2]};
+          const double Xw[3] = {XW(m, 0), XW(m, 1), XW(m, 2)};
           double e[3], p[3];
           // outliers: e->computeError() at the current estimate; the others keep the errors of the last computeActiveErrors
           const float chi2 = (float)po_error(outl[i] ? est : est_err, Xw, kp.x, kp.y, ur, stereo, infoe, cam, e, p);
@@ -491,7 +535,11 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
       info[4] = trials_total;
       info[5] = nInitial - nBad;
     }
-    if (min_matches > 0) {
+    if (source == 2) {
+      __syncthreads();
+      tlm_tail(tb, f, nkp, match, outl, nInitial, min_inliers, lane);
+      if (lane < 16) tb.Tcur[(size_t)f * 16 + lane] = T_out[lane];
+    } else if (min_matches > 0) {
       // "Discard outliers" (src/Tracking.cc:699-711): outliers lose their map point and their flag; the survivors whose
       // point has observations count towards nmatchesMap.  The optimised pose is the frame's pose (pFrame->SetPose).
       __syncthreads();   // T_out written by lane 0
@@ -520,6 +568,7 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
       }
     }
   }
+#undef XW
 }
 
 int launch_pose_opt(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sigma2, int source, int n_frames,

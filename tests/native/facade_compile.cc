@@ -21,6 +21,9 @@ int main() {
   auto popt = &SD_SLAM::Optimizer::PoseOptimization;
   auto twmm = &SD_SLAM::Tracking::TrackWithMotionModel;
   auto twres = &SD_SLAM::Tracking::Result;
+  auto tlm = &SD_SLAM::Tracking::TrackLocalMap;
+  auto tlmres = &SD_SLAM::Tracking::LocalMapResult;
+  if (!tlm || !tlmres) return 5;
   if (!reloc || !loop || !popt || !twmm || !twres) return 4;
   std::printf("facade ok\n");
   return 0;

@@ -480,6 +480,53 @@ def test_track_with_motion_model_decisions(sd, oracle, rig):
     assert {(2, 0), (2, 1), (0, 1)} <= seen and any(s == 1 for s, _ in seen), seen
 
 
+def test_track_local_map_after_motion_model(sd, oracle, rig):
+    """Tracking::TrackLocalMap (src/Tracking.cc:720-751) chained behind TrackWithMotionModel without a host round trip:
+    the local search is closed where the frame match has observations, PoseOptimization runs over the union of both
+    match vectors, mnMatchesInliers decides.  Everything equals the oracle's composition of the stages."""
+    trk, B = rig["trk"], rig["B"]
+    scenes, oras = rig["scenes"], rig["oras"]
+    log_sf = np.log(np.float32(CFG[1]))
+    lasts = [dict(o["last"]) for o in oras]
+    for i, l in enumerate(lasts):       # a third of the last frame's points are not in the map yet (Observations() == 0)
+        l["obs"] = (np.arange(len(l["obs"])) % 3 != i % 3).astype(np.int32)
+    lasts[2]["valid"] = (np.arange(len(lasts[2]["valid"])) < 25).astype(np.uint8)       # frame 2 enters with few frame matches
+    cases = [{k: v[:1000] for k, v in synth.local_map_case(300 + i, oras[i]["ck"], oras[i]["cd"], scenes[i]["T_cur"]).items()} for i in range(B)]
+    cases[3] = {k: v[:12] for k, v in cases[3].items()}                                  # frame 3 has an almost empty local map
+    T0 = [synth.se3_exp((0.004, -0.003, 0.002), (0.05, 0.03, -0.04)) @ s["T_cur"] for s in scenes]
+    trk.set_last(0, lasts)
+    trk.set_local(0, cases)
+    try:
+        for th, min_inl in ((1.0, 30), (3.0, 30), (5.0, 2000)):
+            trk.set_poses(0, [s["T_ref"] for s in scenes], T0)
+            trk.track_with_motion_model(B, th=8.0, mono=True, align_mode=0)
+            fm, _ = trk.get_matches(0, B)
+            T_mm = trk.get_pose_opt(0, B)["T"]
+            trk.track_local_map(B, th=th, min_inliers=min_inl)
+            g, gp, gl = trk.get_local_map(0, B), trk.get_pose_opt(0, B), trk.get_local(0, B)
+            for i in range(B):
+                o = oras[i]
+                n = len(o["ck"])
+                r = oracle.track_local_map(o["ck"], o["cd"], o["tab"], log_sf, BOUNDS, K, T_mm[i], fm[i, :n], lasts[i], cases[i], th=th,
+                                           min_inliers=min_inl)
+                key = (th, i)
+                assert np.array_equal(gl["match"][i, :n], r["local_match"]), key
+                want = np.where(r["local_match"] >= 0, r["local_match"] + 1000, r["frame_match"])
+                assert np.array_equal(g["match"][i, :n], want) and (g["match"][i, n:] == -1).all(), key
+                assert g["n_points"][i] == r["n_points"] and g["n_local"][i] == r["n_local"], key
+                assert np.array_equal(gp["outlier"][i, :n], r["outlier"]), key
+                assert g["n_inliers"][i] == r["n_inliers"] and g["status"][i] == r["status"], (key, g["n_inliers"][i], r["n_inliers"])
+                assert np.abs(gp["T"][i] - r["T"]).max() <= POSE_TOL, (key, np.abs(gp["T"][i] - r["T"]).max())
+                if th == 1.0:
+                    assert (r["status"] == 2) == (i != 3 or r["n_inliers"] >= 30)
+                    if i < 2:
+                        assert r["n_local"] > 100 and r["status"] == 2
+                else:
+                    assert th != 5.0 or r["status"] == 1          # gate above what any frame reaches
+    finally:
+        trk.set_last(0, [o["last"] for o in oras])
+
+
 @pytest.fixture(scope="module")
 def kfmap(sd, oracle):
     """One current frame and 8 keyframes of a small map: six see the current frame's scene from nearby or distant
@@ -671,7 +718,15 @@ def test_tracker_errors_are_loud(sd):
     with pytest.raises(sd.SdError):
         trk.pnp(1, 0.99, 10, 50, 5, 0.4, 5.991, 50)       # minSet != 4
     with pytest.raises(sd.SdError):
-        trk.pose_opt(1, source=2)
+        trk.pose_opt(1, source=3)
+    with pytest.raises(sd.SdError):
+        trk.track_with_motion_model(1, align_mode=2)      # only -1, 0, 1
+    with pytest.raises(sd.SdError):
+        trk.track_with_motion_model(2)                    # only one frame was extracted
+    with pytest.raises(sd.SdError):
+        trk.set_current_broadcast(2)                      # no such frame in the cur extractor
+    with pytest.raises(sd.SdError):
+        trk.relocalize(2, cur_frame=1)                    # frame 1 was not extracted
     big = dict(cand=np.ones(101, np.uint8), Xw=np.zeros((101, 3)), normal=np.zeros((101, 3)), min_dist=np.zeros(101, np.float32),
                max_dist=np.ones(101, np.float32), mf_max_dist=np.ones(101, np.float32), desc=np.zeros((101, 32), np.uint8),
                obs=np.zeros(101, np.int32))
