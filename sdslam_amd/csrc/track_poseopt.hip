@@ -12,11 +12,12 @@
 //   SE3Quat::exp / operator* / map, VertexSE3Expmap::oplusImpl    src/extra/g2o/types/se3quat.h, types_six_dof_expmap.h:73-76
 //
 // Shape: the graph has ONE 6-DoF vertex and up to ~1000 unary edges, so an LM step is two reductions over the
-// edges (robust chi2; 21 + 6 entries of H and b) around a 6x6 solve.  Lane l owns keypoints l, l + 64, ...: it
-// re-derives each edge from the resident arrays (undistorted keypoint, level sigma, matched map point) instead of
-// storing per-edge state, accumulates in fp64 and the wave combines with xor-butterflies (every lane ends with the
-// same bits).  Lane 0 factorises H + lambda I in LDS (pivoted LDLT, Eigen semantics incl. isPositive); all lanes
-// replay the scalar LM logic in lock step.  g2o adds edges in keypoint order and sums them sequentially; the
+// edges (robust chi2; 21 + 6 entries of H and b) around a 6x6 solve.  One frame = one workgroup of 4 waves; thread t
+// owns keypoints t, t + 256, ...: it re-derives each edge from the resident arrays (undistorted keypoint, level sigma,
+// matched map point) instead of storing per-edge state, accumulates in fp64, the waves combine with xor-butterflies
+// and across waves through LDS in a fixed order (every thread ends with the same bits).  Thread 0 factorises
+// H + lambda I in LDS (pivoted LDLT, Eigen semantics incl. isPositive); all threads replay the scalar LM logic in
+// lock step.  g2o adds edges in keypoint order and sums them sequentially; the
 // butterfly order differs, so this stage is compared at a tolerance (pose 1e-5, identical outlier flags), like
 // ImageAlign's H.  Quirks kept: every round restarts from the frame's initial pose; edges are classified with the
 // errors of the last computeActiveErrors (after a rejected trial: the rejected estimate's) -- kept as "the estimate
@@ -24,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstdlib>
 
 #include "orb_internal.h"
 #include "track_internal.h"
@@ -233,16 +235,69 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// One frame = one workgroup of W waves (W = 1 for large batches, where the waves of other frames fill the SIMDs and the
+// replicated scalar LM logic of extra waves would only cost; W = 4 for small batches, where the edge loops are the
+// critical path): the edges are spread over all threads; sums are combined per wave by butterflies and across waves
+// through LDS in a fixed order, so that every thread continues with the same bits.
+constexpr int PO_NRED = 28;
+template <int W>
+struct PoRed {
+  double part[W][PO_NRED];
+  int cnt[W][2];
+};
+template <int N, int W>
+__device__ __forceinline__ void block_sum(double (&v)[N], PoRed<W>& R, int wave, int lane) {
+  static_assert(N <= PO_NRED, "reduction scratch too small");
+#pragma unroll
+  for (int k = 0; k < N; k++) v[k] = wave_sum(v[k]);
+  if (W == 1) return;
+  __syncthreads();   // earlier readers of R are done
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < N; k++) R.part[wave][k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    double t = R.part[0][k];
+#pragma unroll
+    for (int w = 1; w < W; w++) t += R.part[w][k];
+    v[k] = t;
+  }
+}
+// a, b: wave-uniform partial counts
+template <int W>
+__device__ __forceinline__ void block_count2(int& a, int& b, PoRed<W>& R, int wave, int lane) {
+  if (W == 1) return;
+  __syncthreads();
+  if (lane == 0) {
+    R.cnt[wave][0] = a;
+    R.cnt[wave][1] = b;
+  }
+  __syncthreads();
+  int ta = 0, tb2 = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++) {
+    ta += R.cnt[w][0];
+    tb2 += R.cnt[w][1];
+  }
+  a = ta;
+  b = tb2;
+}
+
 // Tracking::TrackLocalMap after PoseOptimization (src/Tracking.cc:730-751): mnMatchesInliers = points of mvpMapPoints that
 // are not outliers and have observations; tracked iff >= min_inliers (30).  Nothing is discarded here.
+template <int W>
 __device__ void tlm_tail(const TrackBuffers& tb, int f, int nkp, const int32_t* match, const uint8_t* outl, int nInitial, int min_inliers,
-                         int lane) {
+                         PoRed<W>& R) {
+  constexpr int PO_THREADS = 64 * W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = tb.max_points;
   const int32_t* obs_lo = tb.obs + (size_t)f * M;
   const int32_t* obs_hi = tb.lm_obs + (size_t)f * M - M;
   int ninl = 0, nloc = 0;
-  for (int i0 = 0; i0 < nkp; i0 += 64) {
-    const int i = i0 + lane;
+  for (int i0 = 0; i0 < nkp; i0 += PO_THREADS) {
+    const int i = i0 + tid;
     bool inl = false, loc = false;
     if (i < nkp && match[i] >= 0) {
       const int m = match[i];
@@ -252,7 +307,8 @@ __device__ void tlm_tail(const TrackBuffers& tb, int f, int nkp, const int32_t* 
     ninl += __popcll(__ballot(inl));
     nloc += __popcll(__ballot(loc));
   }
-  if (lane == 0) {
+  block_count2(ninl, nloc, R, wave, lane);
+  if (tid == 0) {
     tb.tl_info[(size_t)f * 4 + 0] = ninl >= min_inliers ? 2 : 1;
     tb.tl_info[(size_t)f * 4 + 1] = nInitial;
     tb.tl_info[(size_t)f * 4 + 2] = ninl;
@@ -261,12 +317,15 @@ __device__ void tlm_tail(const TrackBuffers& tb, int f, int nkp, const int32_t* 
 }
 
 // source 0: map points of the frame-to-frame match (tb.cur_match -> tb.Xw); 1: of the local-map search (tb.lm_match -> tb.lm_Xw)
-__global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all, TrackBuffers tb,
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all, TrackBuffers tb,
                                                 TrackCam tcam, const float* __restrict__ inv_sigma2, int source, int n_frames,
                                                 int min_matches, int min_inliers) {
   __shared__ double s_A[36], s_b[6], s_x[8];
   __shared__ int s_ok;
-  const int lane = threadIdx.x;
+  constexpr int PO_THREADS = 64 * W;
+  __shared__ PoRed<W> s_red;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
     __syncthreads();
     const int cap = tb.kp_cap, M = tb.max_points;
@@ -292,25 +351,29 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
       // where the keypoint held nothing or a point without observations, src/ORBmatcher.cc:81-83, :114)
       const int32_t* fm = tb.cur_match + (size_t)f * cap;
       const int32_t* lm = tb.lm_match + (size_t)f * cap;
-      for (int i = lane; i < cap; i += 64) match[i] = lm[i] >= 0 ? lm[i] + M : fm[i];
+      for (int i = tid; i < cap; i += PO_THREADS) match[i] = lm[i] >= 0 ? lm[i] + M : fm[i];
       __syncthreads();
     }
     int nInitial = 0;
-    for (int i0 = 0; i0 < nkp; i0 += 64) {
-      const int i = i0 + lane;
+    for (int i0 = 0; i0 < nkp; i0 += PO_THREADS) {
+      const int i = i0 + tid;
       const bool has = i < nkp && match[i] >= 0;
       nInitial += __popcll(__ballot(has));
     }
-    for (int i = lane; i < cap; i += 64) outl[i] = 0;
-    if (lane < 16) T_out[lane] = T_in[lane];
-    if (lane == 0) {
+    {
+      int zero = 0;
+      block_count2(nInitial, zero, s_red, wave, lane);
+    }
+    for (int i = tid; i < cap; i += PO_THREADS) outl[i] = 0;
+    if (tid < 16) T_out[tid] = T_in[tid];
+    if (tid == 0) {
       for (int k = 0; k < 8; k++) info[k] = 0;
       info[0] = nInitial;
     }
     // TrackWithMotionModel: "Not enough matches, tracking failed" returns before PoseOptimization (src/Tracking.cc:691-694)
     const int nm_search = min_matches > 0 ? tb.n_matches[f] : 0;
     if (min_matches > 0 && nm_search < min_matches) {
-      if (lane == 0) {
+      if (tid == 0) {
         tb.tw_info[(size_t)f * 4 + 0] = 0;
         tb.tw_info[(size_t)f * 4 + 1] = nm_search;
         tb.tw_info[(size_t)f * 4 + 2] = 0;
@@ -320,7 +383,7 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
     if (nInitial < 3) {
       if (source == 2) {   // PoseOptimization returns 0 and leaves pose and flags alone; TrackLocalMap still counts
         __syncthreads();
-        tlm_tail(tb, f, nkp, match, outl, nInitial, min_inliers, lane);
+        tlm_tail(tb, f, nkp, match, outl, nInitial, min_inliers, s_red);
       }
       continue;
     }
@@ -336,9 +399,13 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
       est = se3_from_Rt(R0, t0);   // vSE3->setEstimate(Converter::toSE3Quat(pFrame->GetPose()))
       // ---------------- optimizer.optimize(10)
       int n_active = 0;
-      for (int i0 = 0; i0 < nkp; i0 += 64) {
-        const int i = i0 + lane;
+      for (int i0 = 0; i0 < nkp; i0 += PO_THREADS) {
+        const int i = i0 + tid;
         n_active += __popcll(__ballot(i < nkp && match[i] >= 0 && !outl[i]));
+      }
+      {
+        int zero = 0;
+        block_count2(n_active, zero, s_red, wave, lane);
       }
       double lambda = -1., ni = 2.;
       int nBadLM = 0;
@@ -349,7 +416,7 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
         for (int k = 0; k < 21; k++) H[k] = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) b[k] = 0;
-        for (int i = lane; i < nkp; i += 64) {
+        for (int i = tid; i < nkp; i += PO_THREADS) {
           const int m = match[i];
           if (m < 0 || outl[i]) continue;
           const sd_keypoint kp = kps[i];
@@ -402,11 +469,21 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
           }
         }
         est_err = est;
+        {
+          double r[28];
 #pragma unroll
-        for (int k = 0; k < 21; k++) H[k] = wave_sum(H[k]);
+          for (int k = 0; k < 21; k++) r[k] = H[k];
 #pragma unroll
-        for (int k = 0; k < 6; k++) b[k] = wave_sum(b[k]);
-        double currentChi = wave_sum(chi), tempChi = currentChi;
+          for (int k = 0; k < 6; k++) r[21 + k] = b[k];
+          r[27] = chi;
+          block_sum(r, s_red, wave, lane);
+#pragma unroll
+          for (int k = 0; k < 21; k++) H[k] = r[k];
+#pragma unroll
+          for (int k = 0; k < 6; k++) b[k] = r[21 + k];
+          chi = r[27];
+        }
+        double currentChi = chi, tempChi = currentChi;
         const double iniChi = currentChi;
         if (it == 0) {
           double maxDiagonal = 0.;
@@ -424,7 +501,7 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
         do {
           const Se3q backup = est;
           __syncthreads();
-          if (lane == 0) {
+          if (tid == 0) {
             int q = 0;
             for (int a = 0; a < 6; a++)
               for (int c = a; c < 6; c++) {
@@ -445,7 +522,7 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
           est = se3q_mul(se3q_exp(x), est);
           // computeActiveErrors + activeRobustChi2 at the trial estimate
           double c = 0;
-          for (int i = lane; i < nkp; i += 64) {
+          for (int i = tid; i < nkp; i += PO_THREADS) {
             const int m = match[i];
             if (m < 0 || outl[i]) continue;
             const sd_keypoint kp = kps[i];
@@ -463,7 +540,11 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
             }
           }
           est_err = est;
-          tempChi = wave_sum(c);
+          {
+            double r[1] = {c};
+            block_sum(r, s_red, wave, lane);
+            tempChi = r[0];
+          }
           if (!ok2) tempChi = DBL_MAX;
           rho = (currentChi - tempChi);
           double scale = 0.;
@@ -494,8 +575,8 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
       rounds++;
       // ---------------- classify (src/Optimizer.cc:353-398)
       int bad = 0;
-      for (int i0 = 0; i0 < nkp; i0 += 64) {
-        const int i = i0 + lane;
+      for (int i0 = 0; i0 < nkp; i0 += PO_THREADS) {
+        const int i = i0 + tid;
         bool isbad = false;
         if (i < nkp && match[i] >= 0) {
           const int m = match[i];
@@ -512,12 +593,16 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
         }
         bad += __popcll(__ballot(isbad));
       }
+      {
+        int zero = 0;
+        block_count2(bad, zero, s_red, wave, lane);
+      }
       nBad = bad;
       if (round == 2) robust = false;
       if (nInitial < 10) break;   // optimizer.edges().size() < 10
     }
     // ---------------- result
-    if (lane == 0) {
+    if (tid == 0) {
       const double* q = est.q;
       const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
       const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
@@ -537,16 +622,16 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
     }
     if (source == 2) {
       __syncthreads();
-      tlm_tail(tb, f, nkp, match, outl, nInitial, min_inliers, lane);
-      if (lane < 16) tb.Tcur[(size_t)f * 16 + lane] = T_out[lane];
+      tlm_tail(tb, f, nkp, match, outl, nInitial, min_inliers, s_red);
+      if (tid < 16) tb.Tcur[(size_t)f * 16 + tid] = T_out[tid];
     } else if (min_matches > 0) {
       // "Discard outliers" (src/Tracking.cc:699-711): outliers lose their map point and their flag; the survivors whose
       // point has observations count towards nmatchesMap.  The optimised pose is the frame's pose (pFrame->SetPose).
       __syncthreads();   // T_out written by lane 0
       const int32_t* obs = (source == 0 ? tb.obs : tb.lm_obs) + (size_t)f * M;
-      int nmatches = nm_search, nmap = 0;
-      for (int i0 = 0; i0 < nkp; i0 += 64) {
-        const int i = i0 + lane;
+      int ndrop = 0, nmap = 0;
+      for (int i0 = 0; i0 < nkp; i0 += PO_THREADS) {
+        const int i = i0 + tid;
         bool drop = false, inmap = false;
         if (i < nkp && match[i] >= 0) {
           if (outl[i]) {
@@ -557,11 +642,13 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
             inmap = obs[match[i]] > 0;
           }
         }
-        nmatches -= __popcll(__ballot(drop));
+        ndrop += __popcll(__ballot(drop));
         nmap += __popcll(__ballot(inmap));
       }
-      if (lane < 16) tb.Tcur[(size_t)f * 16 + lane] = T_out[lane];
-      if (lane == 0) {
+      block_count2(ndrop, nmap, s_red, wave, lane);
+      const int nmatches = nm_search - ndrop;
+      if (tid < 16) tb.Tcur[(size_t)f * 16 + tid] = T_out[tid];
+      if (tid == 0) {
         tb.tw_info[(size_t)f * 4 + 0] = nmap >= min_inliers ? 2 : 1;
         tb.tw_info[(size_t)f * 4 + 1] = nmatches;
         tb.tw_info[(size_t)f * 4 + 2] = nmap;
@@ -573,8 +660,16 @@ __global__ __launch_bounds__(64) void k_pose_opt(const sd_keypoint* __restrict__
 
 int launch_pose_opt(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sigma2, int source, int n_frames,
                     hipStream_t s, int min_matches, int min_inliers) {
-  hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(64), 0, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam,
-                     d_inv_sigma2, source, n_frames, min_matches, min_inliers);
+  // waves per frame by batch size: SD_POSEOPT_WAVES=1|4 overrides (experiments)
+  static const int forced = getenv("SD_POSEOPT_WAVES") ? atoi(getenv("SD_POSEOPT_WAVES")) : 0;
+  const int waves = forced ? forced : (n_frames <= 256 ? 4 : 1);
+  const sd_keypoint* kps = cur->have_dist ? cur->d_kps_un : cur->d_kps;
+  if (waves == 4)
+    hipLaunchKernelGGL(k_pose_opt<4>, dim3(n_frames), dim3(256), 0, s, kps, cur->d_nout, tb, cam, d_inv_sigma2, source, n_frames, min_matches,
+                       min_inliers);
+  else
+    hipLaunchKernelGGL(k_pose_opt<1>, dim3(n_frames), dim3(64), 0, s, kps, cur->d_nout, tb, cam, d_inv_sigma2, source, n_frames, min_matches,
+                       min_inliers);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }

@@ -58,4 +58,23 @@ for seed in (20,):
     np.savez_compressed(os.path.join(OUT, f"track2_seed{seed}.npz"), undist=und, lm_match=lm["match"], lm_n=lm["n"],
                         lm_in_view=lm["in_view"], lm_level=lm["level"], lm_proj=lm["proj"], po_T=po["T"], po_outlier=po["outlier"],
                         po_n_inliers=po["n_inliers"])
+    # the reference's composite functions on the same scene: TrackWithMotionModel (normal prior; a prior bad enough for
+    # the wider-window retry with align_image_ off) and TrackLocalMap behind the first
+    last3 = dict(last)
+    last3["obs"] = (np.arange(len(last["obs"])) % 3 != 0).astype(np.int32)
+    pc, pr = [oc.level(l) for l in range(8)], [orf.level(l) for l in range(8)]
+    tw = O.track_with_motion_model(pc, pr, tab, ck, cd, BOUNDS, K, s["T_ref"], T0, last3, 8.0, mono=True)
+    T0b = synth.se3_exp((0.008, -0.006, 0.004), (0.1, 0.06, -0.08)) @ s["T_cur"]
+    twb = O.track_with_motion_model(pc, pr, tab, ck, cd, BOUNDS, K, s["T_ref"], T0b, last3, 1.0, mono=True, align_mode=-1)
+    T0c = synth.se3_exp((0.012, -0.009, 0.006), (0.15, 0.09, -0.12)) @ s["T_cur"]
+    twc = O.track_with_motion_model(pc, pr, tab, ck, cd, BOUNDS, K, s["T_ref"], T0c, last3, 1.0, mono=True, align_mode=-1)
+    assert (twb["status"], twb["retried"], twc["status"], twc["retried"]) == (2, 1, 0, 1)
+    tl = O.track_local_map(ck, cd, tab, np.log(np.float32(1.2)), BOUNDS, K, tw["T"], tw["match"], last3, pts, th=1.0)
+    np.savez_compressed(os.path.join(OUT, f"track3_seed{seed}.npz"), T0b=T0b,
+                        tw_info=np.array([tw["status"], tw["nmatches"], tw["nmatches_map"], tw["retried"]]), tw_T=tw["T"], tw_match=tw["match"],
+                        twb_info=np.array([twb["status"], twb["nmatches"], twb["nmatches_map"], twb["retried"]]), twb_T=twb["T"],
+                        twb_match=twb["match"], T0c=T0c,
+                        twc_info=np.array([twc["status"], twc["nmatches"], twc["nmatches_map"], twc["retried"]]), twc_match=twc["match"],
+                        tl_info=np.array([tl["status"], tl["n_points"], tl["n_inliers"], tl["n_local"]]), tl_T=tl["T"],
+                        tl_local_match=tl["local_match"], tl_outlier=tl["outlier"])
 print("golden written to", OUT, sorted(os.listdir(OUT)))
