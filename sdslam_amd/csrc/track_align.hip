@@ -43,9 +43,15 @@ __device__ unsigned long long g_align_prof[16];
 #endif
 
 #define AL_MAXP 300
+#ifndef AL_THREADS
 #define AL_THREADS 256
+#endif
+#ifndef AL_MIN_WAVES
+#define AL_MIN_WAVES 4   // waves per SIMD the register budget is set for (4 workgroups of 256 threads per CU)
+#endif
 #define AL_WAVES (AL_THREADS / 64)
 #define AL_SLOTS ((AL_MAXP * 16 + AL_THREADS - 1) / AL_THREADS)   // pixel slots per thread
+static_assert(AL_SLOTS <= 64, "jvalid is a 64-bit mask");
 
 struct Mat4 { double m[4][4]; };
 
@@ -172,7 +178,7 @@ __device__ void se3_exp(const double* update, double* res) {
   }
 }
 
-__global__ __launch_bounds__(AL_THREADS, 4) void k_align(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr_cur,
+__global__ __launch_bounds__(AL_THREADS, AL_MIN_WAVES) void k_align(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr_cur,
                                                const uint8_t* __restrict__ pyr_ref, TrackBuffers tb, TrackCam cam,
                                                const float* __restrict__ inv_sf, const float* __restrict__ sf, int mode,
                                                int n_frames) {
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(AL_THREADS, 4) void k_align(const OrbPlan* __restri
   float r_patch[AL_SLOTS], r_dx[AL_SLOTS], r_dy[AL_SLOTS];
 #pragma unroll
   for (int k = 0; k < AL_SLOTS; k++) r_patch[k] = r_dx[k] = r_dy[k] = 0.f;
-  unsigned jvalid = 0;
+  unsigned long long jvalid = 0;   // bit k: slot k has a Jacobian at this level (AL_SLOTS <= 64)
 
   APROF(0);
   const int lvl_hi = 4, lvl_lo = (mode == 3) ? 4 : 2;
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(AL_THREADS, 4) void k_align(const OrbPlan* __restri
                                   (w_tl * rp[-1] + w_tr * rp[0] + w_bl * rnext[-1] + w_br * rnext[0]));
                 r_dy[k] = 0.5f * ((w_tl * rnext[0] + w_tr * rnext[1] + w_bl * rnext2[0] + w_br * rnext2[1]) -
                                   (w_tl * rprev[0] + w_tr * rprev[1] + w_bl * rp[0] + w_br * rp[1]));
-                jvalid |= 1u << k;
+                jvalid |= 1ull << k;
               }
             }
           }
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(AL_THREADS, 4) void k_align(const OrbPlan* __restri
               const float res = intensity - r_patch[k];
               chi = res * res * 1.0f;
               nmeas++;
-              if (jvalid & (1u << k)) {
+              if (jvalid & (1ull << k)) {
                 // Jacobian3DToPlane at the reference-frame point, then (dx*row0 + dy*row1)*(fx*scale)
                 const double X = s_xyz[pt * 3], Y = s_xyz[pt * 3 + 1];
                 const double z_inv = 1. / s_xyz[pt * 3 + 2];

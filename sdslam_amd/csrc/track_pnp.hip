@@ -63,7 +63,8 @@ struct LArr {
 
 // ---- one-sided Jacobi SVD (OpenCV 3.2 JacobiSVDImpl_<double>), n <= 12 --------------------
 // The 12 x 12 case (EPnP's M^T M) keeps the matrix and the squared norms W in lane-interleaved LDS
-// (rotation sweeps: jacobi_sweeps12_mem; tail: jacobi_finish12); the small cases are unrolled into
+// (rotation sweeps: jacobi_sweeps12_coop, six lanes per matrix on the independent pairs of an anti-diagonal;
+// tail: jacobi_finish12); the small cases are unrolled into
 // registers (jacobi_svd_small).  Nothing lives in private memory: a dependent scratch access costs
 // a global-memory round trip, which dominated the first version of this kernel.
 // Tail of JacobiSVDImpl_ for the 12 x 12 case (final norms, descending selection sort of the rows,
@@ -291,68 +292,81 @@ __device__ __forceinline__ void jacobi_svd_small(double (&At)[N][M], double (&Wo
 // singular vectors (descending singular values).  A^T == A, so no transpose copy is needed; the
 // right singular vectors are not needed by EPnP and are not formed (they only ride along in
 // JacobiSVDImpl_'s final row swaps).
-// Rotation sweeps; rows are copied to registers per (i, j) pair, everything else stays in LDS.
+// One (i, j) step of JacobiSVDImpl_'s rotation sweeps (for (i) for (j > i) in cyclic order, up to 30 sweeps, stop after a
+// sweep without rotation); rows are copied to registers, everything else stays in LDS.  Returns true when the rows were rotated.
 template <typename Ptr>
-__device__ __noinline__ void jacobi_sweeps12_mem(Ptr A, Ptr W) {
+__device__ __forceinline__ bool jacobi_pair12(Ptr A, Ptr W, int i, int j) {
   const double eps = DBL_EPSILON * 10;
-  for (int i = 0; i < 12; i++) {
-    double sd = 0;
+  const Ptr Ai = A + i * 12, Aj = A + j * 12;
+  double ai[12], aj[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
-      const double t = A[i * 12 + k];
-      sd += t * t;
-    }
-    W[i] = sd;
+  for (int k = 0; k < 12; k++) {
+    ai[k] = Ai[k];
+    aj[k] = Aj[k];
   }
-  for (int iter = 0; iter < 30; iter++) {
-    bool changed = false;
-    for (int i = 0; i < 11; i++)
-      for (int j = i + 1; j < 12; j++) {
-        const Ptr Ai = A + i * 12, Aj = A + j * 12;
-        double ai[12], aj[12];
+  double p = 0;
 #pragma unroll
-        for (int k = 0; k < 12; k++) {
-          ai[k] = Ai[k];
-          aj[k] = Aj[k];
-        }
-        double p = 0;
-#pragma unroll
-        for (int k = 0; k < 12; k++) p += ai[k] * aj[k];
-        const double a = W[i], b = W[j];
-        if (fabs(p) <= eps * sqrt(a * b)) continue;
-        p *= 2;
-        double c, s;
-        const double beta = a - b, gamma = sdsc::hypot_glibc(p, beta);
-        if (beta < 0) {
-          const double delta = (gamma - beta) * 0.5;
-          s = sqrt(delta / gamma);
-          c = p / (gamma * s * 2);
-        } else {
-          c = sqrt((gamma + beta) / (gamma * 2));
-          s = p / (gamma * c * 2);
-        }
-        double na = 0, nb = 0;
-#pragma unroll
-        for (int k = 0; k < 12; k++) {
-          const double t0 = c * ai[k] + s * aj[k];
-          const double t1 = -s * ai[k] + c * aj[k];
-          Ai[k] = t0;
-          Aj[k] = t1;
-          na += t0 * t0;
-          nb += t1 * t1;
-        }
-        W[i] = na;
-        W[j] = nb;
-        changed = true;
-      }
-    if (!changed) break;
+  for (int k = 0; k < 12; k++) p += ai[k] * aj[k];
+  const double a = W[i], b = W[j];
+  if (fabs(p) <= eps * sqrt(a * b)) return false;
+  p *= 2;
+  double c, s;
+  const double beta = a - b, gamma = sdsc::hypot_glibc(p, beta);
+  if (beta < 0) {
+    const double delta = (gamma - beta) * 0.5;
+    s = sqrt(delta / gamma);
+    c = p / (gamma * s * 2);
+  } else {
+    c = sqrt((gamma + beta) / (gamma * 2));
+    s = p / (gamma * c * 2);
   }
+  double na = 0, nb = 0;
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const double t0 = c * ai[k] + s * aj[k];
+    const double t1 = -s * ai[k] + c * aj[k];
+    Ai[k] = t0;
+    Aj[k] = t1;
+    na += t0 * t0;
+    nb += t1 * t1;
+  }
+  W[i] = na;
+  W[j] = nb;
+  return true;
 }
 
+// The sweeps with up to six lanes per matrix.  In the cyclic order (0,1), (0,2), ..., (10,11) a pair only
+// depends on the previous pairs that touched row i or row j; unrolling that recurrence gives pair (i, j) the
+// earliest step i + j, so the pairs of one anti-diagonal (at most six) are independent of each other and a sweep takes
+// 21 steps instead of 66.  Every pair executes exactly the scalar code above on the same inputs as in the sequential
+// order, so the result has the same bits; only independent pairs change places.  Called by ALL 64 lanes of the (single-wave) workgroup: lane
+// g < 6 of a matrix takes the g-th pair of the step; `act` = this lane's matrix exists.  A matrix whose sweep rotated
+// nothing is finished (the sequential loop's `break`).
 template <typename Ptr>
-__device__ void svd_sym12_inplace(Ptr A /* 144 matrix + 12 squared norms */) {
-  jacobi_sweeps12_mem(A, A + 144);
-  jacobi_finish12(A, A + 144);
+__device__ __noinline__ void jacobi_sweeps12_coop(Ptr A, Ptr W, int g, bool act, unsigned long long group_mask) {
+  if (act && g < 6)
+    for (int i = g; i < 12; i += 6) {
+      double sd = 0;
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        const double t = A[i * 12 + k];
+        sd += t * t;
+      }
+      W[i] = sd;
+    }
+  __syncthreads();
+  bool live = act;
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+    for (int st = 1; st <= 21; st++) {
+      const int i = max(0, st - 11) + g, j = st - i;
+      if (live && g < 6 && i < j) changed |= jacobi_pair12(A, W, i, j);
+      __syncthreads();   // one wave: orders this step's LDS writes before the next step's reads
+    }
+    const unsigned long long any = __ballot(changed);
+    live = live && (any & group_mask) != 0;
+    if (!__any(live)) break;
+  }
 }
 
 // cvSVD of a row-major 3 x 3 matrix: Ut rows = left vectors, Vt rows = right vectors
@@ -686,8 +700,9 @@ __device__ __forceinline__ double epnp_reproj_term(const double Rv[3][3], const 
 // ---- EPnP on a RANSAC minimal set (n = 4) -------------------------------------------------------
 // Called by ALL 64 lanes.  Lane layout: hypothesis h = lane % PNP_CHUNK, beta variant = lane /
 // PNP_CHUNK + 1 (lanes >= 3 * PNP_CHUNK idle).  The three lanes of a hypothesis compute the cheap
-// front part redundantly (lock-step, so it costs nothing), the variant-1 lane alone runs the
-// 12 x 12 SVD and writes L into the hypothesis' LDS view, then each lane follows its own
+// front part redundantly (lock-step, so it costs nothing), the variant-1 lane builds M^T M, six lanes
+// per hypothesis run the 12 x 12 Jacobi sweeps (jacobi_sweeps12_coop), the variant-1 lane finishes the SVD
+// and writes L into the hypothesis' LDS view, then each lane follows its own
 // find_betas variant / Gauss-Newton / R,t / reprojection error.  Returns that variant's error.
 template <typename Ptr>
 __device__ __noinline__ double epnp_minimal(bool active, int variant, const double* pws, const double* us, const EpnpCam cam,
@@ -742,7 +757,15 @@ __device__ __noinline__ double epnp_minimal(bool active, int variant, const doub
     for (int a = 0; a < 12; a++)
       for (int b = 0; b < a; b++) ut[a * 12 + b] = ut[b * 12 + a];
     PROF(2);
-    svd_sym12_inplace(ut);
+  }
+  {
+    // 12 x 12 SVD: sweeps with six lanes per hypothesis (lanes h, h + 8, ..., h + 40 share hypothesis h's LDS view),
+    // tail on the variant-1 lane
+    const int lane = threadIdx.x, h = lane % PNP_CHUNK, g = lane / PNP_CHUNK;
+    __syncthreads();
+    const bool act_h = __shfl((int)active, h) != 0;   // lane h is the variant-1 lane of hypothesis h
+    jacobi_sweeps12_coop(ut, ut + 144, g, act_h, 0x0000010101010101ull << h);
+    if (active && variant == 1) jacobi_finish12(ut, ut + 144);
     PROF(3);
   }
   epnp_L_rho(ut, cws, L, rho, active && variant == 1);
@@ -907,10 +930,10 @@ __device__ __noinline__ double epnp_refit_wave(int n, const double* pws, const d
   __syncthreads();
   PROF(18);
   double rho[6];
-  if (lane == 0) {
-    for (int i = 0; i < 144; i++) ut[i] = mtm[i];
-    svd_sym12_inplace(ut);
-  }
+  for (int i = lane; i < 144; i += 64) ut[i] = mtm[i];
+  __syncthreads();
+  jacobi_sweeps12_coop(ut, ut + 144, lane, true, 0x3full);   // six lanes on the one matrix
+  if (lane == 0) jacobi_finish12(ut, ut + 144);
   PROF(19);
   epnp_L_rho(ut, cws, L, rho, lane == 0);
   __syncthreads();
