@@ -527,6 +527,57 @@ def test_track_local_map_after_motion_model(sd, oracle, rig):
         trk.set_last(0, [o["last"] for o in oras])
 
 
+def test_track_with_motion_model_rgbd(sd, oracle, rig):
+    """The same call on RGB-D frames (bMono = false): mvuRight from the depth image gates the search
+    (src/ORBmatcher.cc:1020-1025) and adds stereo edges to PoseOptimization; results equal the oracle's composition."""
+    trk, B = rig["trk"], rig["B"]
+    scenes, oras = rig["scenes"], rig["oras"]
+    bf = 4.0
+    mb = np.float32(bf) / np.float32(K[0])
+    depth = np.zeros((B, 480, 640), np.float32)
+    for i, s in enumerate(scenes):      # depth of the scene surface along each pixel's ray, holes every 5th column
+        v, u = np.mgrid[0:480, 0:640].astype(np.float64)
+        R, t = s["T_cur"][:3, :3], s["T_cur"][:3, 3]
+        rays = np.stack([(u - K[2]) / K[0], (v - K[3]) / K[1], np.ones_like(u)], -1)
+        Ow = -R.T @ t
+        Xw = synth.intersect_surface(Ow, rays @ R, 2.0)
+        zc = (Xw @ R.T + t)[..., 2]
+        depth[i] = zc.astype(np.float32)
+        depth[i, :, ::5] = 0
+    T0 = [synth.se3_exp((0.004, -0.003, 0.002), (0.05, 0.03, -0.04)) @ s["T_cur"] for s in scenes]
+    try:
+        trk.set_camera(*K, bf, BOUNDS)
+        trk.stereo_from_depth(depth)
+        ur, _ = trk.get_stereo(0, B)
+        for align_mode, th in ((0, 8.0), (-1, 2.0)):
+            trk.set_poses(0, [s["T_ref"] for s in scenes], T0)
+            T_al = None
+            if align_mode >= 0:
+                trk.align(B, align_mode)
+                T_al = trk.get_align(0, B)["T"]
+                trk.set_poses(0, [s["T_ref"] for s in scenes], T0)
+            trk.track_with_motion_model(B, th=th, mono=False, align_mode=align_mode)
+            tw, gp, (cm, nm) = trk.get_tracked(0, B), trk.get_pose_opt(0, B), trk.get_matches(0, B)
+            for i in range(B):
+                o = oras[i]
+                n = len(o["ck"])
+                assert (ur[i, :n] >= 0).sum() > 300 and (ur[i, :n] < 0).sum() > 50       # stereo and mono edges
+                pc = [o["oc"].level(l) for l in range(8)]
+                pr = [o["orf"].level(l) for l in range(8)]
+                r = oracle.track_with_motion_model(pc, pr, o["tab"], o["ck"], o["cd"], BOUNDS, K, scenes[i]["T_ref"], T0[i], o["last"], th,
+                                                   mono=False, align_mode=align_mode, u_right=ur[i, :n], mbf=bf, mb=mb,
+                                                   T_aligned=None if T_al is None else T_al[i])
+                key = (align_mode, i)
+                assert (tw["status"][i], tw["retried"][i], tw["nmatches"][i], tw["nmatches_map"][i]) == \
+                       (r["status"], r["retried"], r["nmatches"], r["nmatches_map"]), key
+                assert np.array_equal(cm[i, :n], r["match"]), key
+                assert np.abs(gp["T"][i] - r["T"]).max() <= POSE_TOL, (key, np.abs(gp["T"][i] - r["T"]).max())
+                assert r["status"] == 2
+    finally:
+        trk.set_camera(*K, 0.0, BOUNDS)
+        trk.stereo_from_depth(np.zeros((B, 480, 640), np.float32))
+
+
 @pytest.fixture(scope="module")
 def kfmap(sd, oracle):
     """One current frame and 8 keyframes of a small map: six see the current frame's scene from nearby or distant
