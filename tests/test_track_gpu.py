@@ -660,6 +660,45 @@ def test_relocalization_over_all_keyframes(sd, oracle, kfmap):
         trk.set_last(0, [k["last"] for k in m["kfs"]])
 
 
+def test_relocalization_rgbd_broadcast(sd, oracle, kfmap):
+    """RGB-D relocalisation: the ONE current frame's mvuRight row (from its depth image) serves every keyframe slot --
+    search gates and stereo edges equal the oracle's per-keyframe sequence."""
+    m, trk, NK = kfmap, kfmap["trk"], kfmap["NK"]
+    bf = 4.0
+    mb = np.float32(bf) / np.float32(K[0])
+    v, u = np.mgrid[0:480, 0:640].astype(np.float64)
+    R, t = m["T_cur"][:3, :3], m["T_cur"][:3, 3]
+    rays = np.stack([(u - K[2]) / K[0], (v - K[3]) / K[1], np.ones_like(u)], -1)
+    Xs = synth.intersect_surface(-R.T @ t, rays @ R, 2.0)
+    depth = (Xs @ R.T + t)[..., 2].astype(np.float32)
+    depth[:, ::4] = 0
+    n = len(m["ck"])
+    try:
+        trk.set_camera(*K, bf, BOUNDS)
+        trk.stereo_from_depth(depth[None])                # one current frame in the cur extractor
+        ur = trk.get_stereo(0, 1)[0][0, :n]
+        assert (ur >= 0).sum() > 300 and (ur < 0).sum() > 100
+        trk.set_poses(0, m["T_kf"], m["T_kf"])
+        winner, st = trk.relocalize(NK, cur_frame=0, th=15.0, mono=False)
+        ga, (cm, nm), gp = trk.get_align(0, NK), trk.get_matches(0, NK), trk.get_pose_opt(0, NK)
+        expect = -1
+        for i in range(NK):
+            k = m["kfs"][i]
+            nmo, ocm = oracle.search_by_projection(m["ck"], m["cd"], m["tab"]["sf"], BOUNDS, K, ga["T"][i], m["T_kf"][i], k["last"],
+                                                   th=15.0, mono=False, check_ori=True, u_right=ur, mbf=bf, mb=mb)
+            assert nm[i] == nmo == st[i, 1] and np.array_equal(cm[i, :n], ocm), i
+            rp = oracle.pose_optimization(m["ck"], ocm >= 0, k["last"]["Xw"][np.maximum(ocm, 0)], m["tab"]["inv_sigma2"], K, ga["T"][i],
+                                          u_right=ur, bf=bf)
+            assert gp["n_inliers"][i] == rp["n_inliers"] == st[i, 2] and np.array_equal(gp["outlier"][i, :n], rp["outlier"]), i
+            assert np.abs(gp["T"][i] - rp["T"]).max() <= POSE_TOL
+            if expect < 0 and st[i, 0] and nmo >= 20 and rp["n_inliers"] >= 10:
+                expect = i
+        assert winner == expect and winner >= 0
+    finally:
+        trk.set_camera(*K, 0.0, BOUNDS)
+        trk.stereo_from_depth(np.zeros((1, 480, 640), np.float32))
+
+
 def test_detect_loop_candidates(sd, oracle, kfmap):
     """LoopClosing::DetectLoop's candidate search (src/LoopClosing.cc:115-149): KF-KF ImageAlign of the current keyframe
     against all keyframes in one launch, then the reference's loop (exclusions, skip-after-failure, 1.5 x best)."""
