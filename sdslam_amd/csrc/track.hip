@@ -143,6 +143,10 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
     std::vector<float> neg((size_t)B * K, -1.f);
     hipError_t e0 = hipMemcpy(tb.uright, neg.data(), neg.size() * 4, hipMemcpyHostToDevice);
     if (e0 == hipSuccess) e0 = hipMemcpy(tb.depth, neg.data(), neg.size() * 4, hipMemcpyHostToDevice);
+    // "no map point" until a search has run (a TrackLocalMap / PoseOptimization called first must not see index 0 everywhere)
+    if (e0 == hipSuccess) e0 = hipMemset(tb.cur_match, 0xFF, (size_t)B * K * 4);
+    if (e0 == hipSuccess) e0 = hipMemset(tb.lm_match, 0xFF, (size_t)B * K * 4);
+    if (e0 == hipSuccess) e0 = hipMemset(tb.un_match, 0xFF, (size_t)B * K * 4);
     if (e0 != hipSuccess) { set_error(std::string("sd_track_create: ") + hipGetErrorString(e0)); rc = SD_ERR_HIP; }
   }
   if (rc == SD_OK) {

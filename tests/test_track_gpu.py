@@ -786,6 +786,28 @@ def test_degenerate_frames_through_the_whole_chain(sd, oracle):
     assert lm["in_view"][0].sum() > 500 and not lm["in_view"][1].any()      # points project into the flat frame, nothing to match
 
 
+def test_fresh_tracker_has_no_matches(sd, oracle):
+    """Before any search has run the match vectors mean "no map point": PoseOptimization / TrackLocalMap called first
+    find nothing to optimise instead of reading point 0 for every keypoint."""
+    cur = sd.ORBextractor(*CFG, 640, 480, 1)
+    ref = sd.ORBextractor(*CFG, 640, 480, 1)
+    img = synth.make_image(9)
+    cur.extract_batch(img[None])
+    ref.extract_batch(img[None])
+    trk = sd.Tracker(cur, ref, max_points=200, max_batch=1)
+    trk.set_camera(*K, 0.0, BOUNDS)
+    trk.set_poses(0, [np.eye(4)], [np.eye(4)])
+    cm, nm = trk.get_matches(0, 1)
+    assert (cm == -1).all()
+    for source in (0, 1, 2):
+        trk.pose_opt(1, source=source)
+        g = trk.get_pose_opt(0, 1)
+        assert g["n_initial"][0] == 0 and g["n_inliers"][0] == 0 and np.abs(g["T"][0] - np.eye(4)).max() == 0
+    trk.track_local_map(1)
+    tl = trk.get_local_map(0, 1)
+    assert tl["status"][0] == 1 and tl["n_points"][0] == 0 and (tl["match"] == -1).all()
+
+
 def test_tracker_errors_are_loud(sd):
     """Capacity / argument violations come back as SdError, never as silent truncation."""
     cur = sd.ORBextractor(*CFG, 640, 480, 2)
