@@ -14,6 +14,11 @@ per GPU (torch.distributed / RCCL); frames are independent, so ranks share nothi
 path (weak scaling); the fixed-size per-frame pose records are all-gathered once.
 Rank 0 prints ONE JSON line.
 
+Variants of the step (same metric name, `config.pose_solver` says which): --pose-solver poseopt replaces PnP RANSAC by
+Optimizer::PoseOptimization (what the reference's TrackWithMotionModel really calls, SURVEY D1); motion_model runs the
+whole Tracking::TrackWithMotionModel as one device-side call; track adds Tracking::TrackLocalMap over a ~1000-point
+local map.  --orb-only times the extraction alone, --res WxH other frame sizes, --batch 1 the single-frame latency.
+
 Extra objects in the line:
   roofline     -- the dominant kernel stage: algorithmic bytes per launch / its mean
                   duration, measured with HIP events on the launch stream inside the timed region

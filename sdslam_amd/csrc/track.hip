@@ -1,6 +1,9 @@
-// sd_track_*: batched TrackWithMotionModel context (ImageAlign -> SearchByProjection -> PnP)
+// sd_track_*: batched TrackWithMotionModel context (ImageAlign -> SearchByProjection -> pose solve)
 // over two resident extractor handles (current frames, last frames).  Host side only; the
-// kernels live in track_align.hip / track_match.hip / track_pnp.hip.
+// kernels live in track_align.hip / track_match.hip / track_pnp.hip / track_poseopt.hip.
+// Besides the stage calls: whole-function calls that keep the reference's per-frame decisions on
+// the device (sd_track_with_motion_model, sd_track_local_map) and the one-frame-against-all-
+// keyframes calls (sd_track_relocalize, sd_track_detect_loop) built on the broadcast current frame.
 //
 // Call sequence of the reference this mirrors (src/Tracking.cc:654-718):
 //   ImageAlign::ComputePose(cur, last)            -> sd_track_align
