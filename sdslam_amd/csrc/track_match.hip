@@ -62,13 +62,17 @@ struct MatchLds {
   const uint32_t* s_kclaim;   // bit idx: keypoint idx already held such a point before the call (may be null)
 };
 
-template <int MODE>
+// GL = lanes that work on one point: 64 (the whole wave; `lane`, `lt` as usual, gm = ~0) or 32 (a wave handles two points,
+// one per half: `lane` = lane within the half, `lt` = the lower lanes OF THE HALF and `gm` = the half's lanes, both as
+// bit masks of the 64-bit wave ballot).  The halves diverge freely; a ballot only ever carries the active lanes.
+template <int MODE, int GL = 64>
 __device__ __forceinline__ uint32_t match_window(float u, float v, float radius, int minLevel, int maxLevel, float ur,
                                                  const uint8_t* __restrict__ dmp /* 32-byte map point descriptor */,
                                                  const sd_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                  const float* __restrict__ uright, const MatchLds& S, const TrackCam& cam, float invW,
                                                  float invH, uint32_t* list, int lane, unsigned long long lt, int* seq_total,
-                                                 long long above = -1 /* MODE 2: only keys greater than this */) {
+                                                 long long above = -1 /* MODE 2: only keys greater than this */,
+                                                 unsigned long long gm = ~0ull) {
   uint32_t best = 0x7FFFFFFFu;
   *seq_total = 0;
   const int nMinCellX = max(0, (int)floorf((u - cam.min_x - radius) * invW));
@@ -88,7 +92,7 @@ __device__ __forceinline__ uint32_t match_window(float u, float v, float radius,
   int seq0 = 0, w = 0;
   for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
     const int a = S.s_cstart[ix * GRID_ROWS + nMinCellY], b = S.s_cstart[ix * GRID_ROWS + nMaxCellY + 1];
-    for (int e0 = a; e0 < b; e0 += 64) {
+    for (int e0 = a; e0 < b; e0 += GL) {
       const int e = e0 + lane;
       bool okc = false;
       int idx = 0;
@@ -116,7 +120,7 @@ __device__ __forceinline__ uint32_t match_window(float u, float v, float radius,
         }
       }
       if (MODE == 0) {
-        w += __popcll(__ballot(okc));
+        w += __popcll(__ballot(okc) & gm);
       } else {
         uint32_t key = 0;
         if (okc) {
@@ -130,7 +134,7 @@ __device__ __forceinline__ uint32_t match_window(float u, float v, float radius,
         if (MODE == 1) {
           const unsigned long long bal = __ballot(okc);
           if (okc) list[w + __popcll(bal & lt)] = key;
-          w += __popcll(bal);
+          w += __popcll(bal & gm);
         }
       }
     }
@@ -141,13 +145,13 @@ __device__ __forceinline__ uint32_t match_window(float u, float v, float radius,
 }
 
 // a16 / a17: projection of last-frame point i (src/ORBmatcher.cc:974-1004) and its window
-template <int MODE>
+template <int MODE, int GL = 64>
 __device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                 const double* __restrict__ Xw, const uint8_t* __restrict__ mp_desc,
                                                 const int32_t* __restrict__ l_oct, const float* __restrict__ uright,
                                                 const MatchLds& S, const MatchGeom& G, const TrackCam& cam,
                                                 const float* __restrict__ sf, uint32_t* list, int lane, unsigned long long lt,
-                                                int* seq_total) {
+                                                int* seq_total, unsigned long long gm = ~0ull) {
   const double xw = Xw[(size_t)i * 3], yw = Xw[(size_t)i * 3 + 1], zw = Xw[(size_t)i * 3 + 2];
   const double X = (G.R[0][0] * xw + G.R[0][1] * yw + G.R[0][2] * zw) + G.t[0];
   const double Y = (G.R[1][0] * xw + G.R[1][1] * yw + G.R[1][2] * zw) + G.t[1];
@@ -165,8 +169,8 @@ __device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __rest
   const int minLevel = G.bForward ? nLastOctave : (G.bBackward ? 0 : nLastOctave - 1);
   const int maxLevel = G.bForward ? -1 : (G.bBackward ? nLastOctave : nLastOctave + 1);
   const float ur = u - cam.bf * invzc;
-  return match_window<MODE>(u, v, radius, minLevel, maxLevel, ur, mp_desc + (size_t)i * 32, kps, desc, uright, S, cam, G.invW, G.invH, list,
-                            lane, lt, seq_total);
+  return match_window<MODE, GL>(u, v, radius, minLevel, maxLevel, ur, mp_desc + (size_t)i * 32, kps, desc, uright, S, cam, G.invW, G.invH,
+                                list, lane, lt, seq_total, -1, gm);
 }
 
 // Dynamic LDS layout (KP2 = power of two >= keypoint capacity, MP = max_points):
@@ -295,26 +299,35 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
   const MatchLds SL = {s_key, s_cstart, s_match, s_obs, nullptr};
   // ---- phase 1 (all waves, one wave per last-frame point): candidate keys into the LDS list.
   // s_pt[i] = 0 (nothing to do) | offset << 16 | count | 0xFFFFFFFF (list full: evaluate in phase 2)
-  for (int i0 = 0; i0 < n_last; i0 += MT_WAVES) {
-    const int i = i0 + wave;
-    if (i >= n_last) break;
-    uint32_t pc = 0;
-    if ((s_valid[i >> 5] >> (i & 31)) & 1u) {
-      int seq = 0;
-      const int cnt = (int)match_point<0>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, nullptr, lane, lt, &seq);
-      if (cnt > 0) {
-        int off = 0;
-        if (lane == 0) off = atomicAdd(s_nlist, cnt);
-        off = __shfl(off, 0);
-        if (off + cnt > MT_LIST_CAP || seq >= 2048 || cnt > 0xffff) {
-          pc = 0xFFFFFFFFu;
-        } else {
-          match_point<1>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, s_list + off, lane, lt, &seq);
-          pc = ((uint32_t)off << 16) | (uint32_t)cnt;
+  // Two points per wave, one per 32-lane half: a point's window rarely holds more than 32 candidates, and a wave is one
+  // dependent chain of loads per point (map point -> keypoints of the window -> their descriptors), so two chains in flight
+  // per wave nearly halve the phase.
+  {
+    const int half = lane >> 5, glane = lane & 31;
+    const unsigned long long gm = 0xFFFFFFFFull << (32 * half);
+    const unsigned long long glt = ((1ull << glane) - 1ull) << (32 * half);
+    for (int i0 = 0; i0 < n_last; i0 += 2 * MT_WAVES) {
+      const int i = i0 + 2 * wave + half;
+      if (i < n_last) {
+        uint32_t pc = 0;
+        if ((s_valid[i >> 5] >> (i & 31)) & 1u) {
+          int seq = 0;
+          const int cnt = (int)match_point<0, 32>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, nullptr, glane, glt, &seq, gm);
+          if (cnt > 0) {
+            int off = 0;
+            if (glane == 0) off = atomicAdd(s_nlist, cnt);
+            off = __shfl(off, 32 * half);
+            if (off + cnt > MT_LIST_CAP || seq >= 2048 || cnt > 0xffff) {
+              pc = 0xFFFFFFFFu;
+            } else {
+              match_point<1, 32>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, s_list + off, glane, glt, &seq, gm);
+              pc = ((uint32_t)off << 16) | (uint32_t)cnt;
+            }
+          }
         }
+        if (glane == 0) s_pt[i] = pc;
       }
     }
-    if (lane == 0) s_pt[i] = pc;
   }
   __syncthreads();
   if (tid >= 64) return;   // one wavefront runs the order-dependent assignment loop
@@ -572,33 +585,39 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
   __syncthreads();   // also makes the o_* stores of this workgroup visible to its own later loads
   const MatchLds SL = {s_key, s_cstart, s_match, s_obs, s_kclaim};
   const bool bFactor = th != 1.0f;
-  // ---- phase 1: candidate lists
-  for (int i0 = 0; i0 < n_loc; i0 += MT_WAVES) {
-    const int i = i0 + wave;
-    if (i >= n_loc) break;
-    uint32_t pc = 0;
-    if (o_inview[i]) {
-      float r = o_cos[i] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos
-      if (bFactor) r *= th;
-      const int lvl = o_level[i];
-      const float radius = r * sf[lvl];
-      int seq = 0;
-      const int cnt = (int)match_window<0>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], radius, lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
-                                           mp_desc + (size_t)i * 32, kps, desc, uright, SL, cam, invW, invH, nullptr, lane, lt, &seq);
-      if (cnt > 0) {
-        int off = 0;
-        if (lane == 0) off = atomicAdd(s_nlist, cnt);
-        off = __shfl(off, 0);
-        if (off + cnt > MT_LIST_CAP || seq >= 2048 || cnt > 0xffff) {
-          pc = 0xFFFFFFFFu;
-        } else {
-          match_window<1>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], radius, lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
-                          mp_desc + (size_t)i * 32, kps, desc, uright, SL, cam, invW, invH, s_list + off, lane, lt, &seq);
-          pc = ((uint32_t)off << 16) | (uint32_t)cnt;
+  // ---- phase 1: candidate lists, two points per wave (one per 32-lane half, see k_match)
+  {
+    const int half = lane >> 5, glane = lane & 31;
+    const unsigned long long gm = 0xFFFFFFFFull << (32 * half);
+    const unsigned long long glt = ((1ull << glane) - 1ull) << (32 * half);
+    for (int i0 = 0; i0 < n_loc; i0 += 2 * MT_WAVES) {
+      const int i = i0 + 2 * wave + half;
+      if (i < n_loc) {
+        uint32_t pc = 0;
+        if (o_inview[i]) {
+          float r = o_cos[i] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos
+          if (bFactor) r *= th;
+          const int lvl = o_level[i];
+          const float radius = r * sf[lvl];
+          int seq = 0;
+          const int cnt = (int)match_window<0, 32>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], radius, lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
+                                                   mp_desc + (size_t)i * 32, kps, desc, uright, SL, cam, invW, invH, nullptr, glane, glt, &seq, -1, gm);
+          if (cnt > 0) {
+            int off = 0;
+            if (glane == 0) off = atomicAdd(s_nlist, cnt);
+            off = __shfl(off, 32 * half);
+            if (off + cnt > MT_LIST_CAP || seq >= 2048 || cnt > 0xffff) {
+              pc = 0xFFFFFFFFu;
+            } else {
+              match_window<1, 32>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], radius, lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
+                                  mp_desc + (size_t)i * 32, kps, desc, uright, SL, cam, invW, invH, s_list + off, glane, glt, &seq, -1, gm);
+              pc = ((uint32_t)off << 16) | (uint32_t)cnt;
+            }
+          }
         }
+        if (glane == 0) s_pt[i] = pc;
       }
     }
-    if (lane == 0) s_pt[i] = pc;
   }
   __syncthreads();
   if (tid >= 64) return;
