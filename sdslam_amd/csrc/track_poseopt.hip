@@ -208,6 +208,18 @@ __device__ __noinline__ int ldlt6_solve_sign(double* A, const double* b, double*
 
 struct PoCam { double fx, fy, cx, cy, bf; };
 
+// One unary edge as the kernel re-derives it from the resident arrays.  The loads behind it form a dependent chain
+// (match index -> map point; keypoint -> octave -> sigma), so the edge loops fetch PO_U edges with straight-line,
+// index-clamped loads before touching any of them: PO_U chains in flight per thread instead of one.
+constexpr int PO_U = 4;
+struct PoEdge {
+  int m;        // map point index, < 0: keypoint without map point (or beyond the keypoint count)
+  int outl;     // current mvbOutlier flag
+  float x, y, ur;
+  double info;  // invSigma2 of the keypoint's octave
+  double Xw[3];
+};
+
 // error of one edge at estimate T; returns chi2 (= invSigma2 * |e|^2); e[] filled
 __device__ __forceinline__ double po_error(const Se3q& T, const double* Xw, double ox, double oy, double our, bool stereo, double info,
                                            const PoCam& cam, double* e, double* p) {
@@ -345,6 +357,32 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
     const PoCam cam = {(double)tcam.ffx, (double)tcam.ffy, (double)tcam.fcx, (double)tcam.fcy, (double)tcam.bf};
     const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);   // const float delta = sqrt(..)
     const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+    auto load_edges = [&](int i0, PoEdge (&E)[PO_U]) {
+      int ic[PO_U];
+#pragma unroll
+      for (int u = 0; u < PO_U; u++) {
+        const int i = i0 + u * PO_THREADS;
+        ic[u] = min(i, max(nkp - 1, 0));
+        const int mm = match[ic[u]];
+        E[u].m = (i < nkp) ? mm : -1;
+        E[u].outl = outl[ic[u]];
+      }
+      int oct[PO_U];
+#pragma unroll
+      for (int u = 0; u < PO_U; u++) {
+        const int mc = max(E[u].m, 0);
+        const sd_keypoint kp = kps[ic[u]];
+        E[u].x = kp.x;
+        E[u].y = kp.y;
+        oct[u] = kp.octave;
+        E[u].ur = uright[ic[u]];
+        E[u].Xw[0] = XW(mc, 0);
+        E[u].Xw[1] = XW(mc, 1);
+        E[u].Xw[2] = XW(mc, 2);
+      }
+#pragma unroll
+      for (int u = 0; u < PO_U; u++) E[u].info = (double)inv_sigma2[oct[u]];
+    };
 
     if (source == 2) {
       // mvpMapPoints after Tracking::SearchLocalPoints: a local match replaces whatever the keypoint held (it is only made
@@ -416,16 +454,19 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
         for (int k = 0; k < 21; k++) H[k] = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) b[k] = 0;
-        for (int i = tid; i < nkp; i += PO_THREADS) {
-          const int m = match[i];
-          if (m < 0 || outl[i]) continue;
-          const sd_keypoint kp = kps[i];
-          const float ur = uright[i];
+        for (int i0 = tid; i0 < nkp; i0 += PO_THREADS * PO_U) {
+         PoEdge E[PO_U];
+         load_edges(i0, E);
+#pragma unroll
+         for (int u = 0; u < PO_U; u++) {
+          const PoEdge& ed = E[u];
+          if (ed.m < 0 || ed.outl) continue;
+          const float ur = ed.ur;
           const bool stereo = !(ur < 0);
-          const double infoe = (double)inv_sigma2[kp.octave];
-          const double Xw[3] = {XW(m, 0), XW(m, 1), XW(m, 2)};
+          const double infoe = ed.info;
+          const double* Xw = ed.Xw;
           double e[3], p[3];
-          const double c2 = po_error(est, Xw, kp.x, kp.y, ur, stereo, infoe, cam, e, p);
+          const double c2 = po_error(est, Xw, ed.x, ed.y, ur, stereo, infoe, cam, e, p);
           double rho1 = 1.0;
           if (robust) {
             const double delta = stereo ? deltaStereo : deltaMono, dsqr = delta * delta;
@@ -467,6 +508,7 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
 #pragma unroll
             for (int c = a; c < 6; c++) H[q++] += (J[0][a] * (wi * J[0][c]) + J[1][a] * (wi * J[1][c])) + J[2][a] * (wi * J[2][c]);
           }
+         }
         }
         est_err = est;
         {
@@ -522,21 +564,22 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
           est = se3q_mul(se3q_exp(x), est);
           // computeActiveErrors + activeRobustChi2 at the trial estimate
           double c = 0;
-          for (int i = tid; i < nkp; i += PO_THREADS) {
-            const int m = match[i];
-            if (m < 0 || outl[i]) continue;
-            const sd_keypoint kp = kps[i];
-            const float ur = uright[i];
-            const bool stereo = !(ur < 0);
-            const double infoe = (double)inv_sigma2[kp.octave];
-            const double Xw[3] = {XW(m, 0), XW(m, 1), XW(m, 2)};
-            double e[3], p[3];
-            const double c2 = po_error(est, Xw, kp.x, kp.y, ur, stereo, infoe, cam, e, p);
-            if (robust) {
-              const double delta = stereo ? deltaStereo : deltaMono, dsqr = delta * delta;
-              c += (c2 <= dsqr) ? c2 : (2 * sqrt(c2) * delta - dsqr);
-            } else {
-              c += c2;
+          for (int i0 = tid; i0 < nkp; i0 += PO_THREADS * PO_U) {
+            PoEdge E[PO_U];
+            load_edges(i0, E);
+#pragma unroll
+            for (int u = 0; u < PO_U; u++) {
+              const PoEdge& ed = E[u];
+              if (ed.m < 0 || ed.outl) continue;
+              const bool stereo = !(ed.ur < 0);
+              double e[3], p[3];
+              const double c2 = po_error(est, ed.Xw, ed.x, ed.y, ed.ur, stereo, ed.info, cam, e, p);
+              if (robust) {
+                const double delta = stereo ? deltaStereo : deltaMono, dsqr = delta * delta;
+                c += (c2 <= dsqr) ? c2 : (2 * sqrt(c2) * delta - dsqr);
+              } else {
+                c += c2;
+              }
             }
           }
           est_err = est;
