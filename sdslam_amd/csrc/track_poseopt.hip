@@ -618,23 +618,24 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
       rounds++;
       // ---------------- classify (src/Optimizer.cc:353-398)
       int bad = 0;
-      for (int i0 = 0; i0 < nkp; i0 += PO_THREADS) {
-        const int i = i0 + tid;
-        bool isbad = false;
-        if (i < nkp && match[i] >= 0) {
-          const int m = match[i];
-          const sd_keypoint kp = kps[i];
-          const float ur = uright[i];
-          const bool stereo = !(ur < 0);
-          const double infoe = (double)inv_sigma2[kp.octave];
-          const double Xw[3] = {XW(m, 0), XW(m, 1), XW(m, 2)};
-          double e[3], p[3];
-          // outliers: e->computeError() at the current estimate; the others keep the errors of the last computeActiveErrors
-          const float chi2 = (float)po_error(outl[i] ? est : est_err, Xw, kp.x, kp.y, ur, stereo, infoe, cam, e, p);
-          isbad = chi2 > (stereo ? chi2Stereo : chi2Mono);
-          outl[i] = isbad ? 1 : 0;
+      for (int i0 = tid; i0 < nkp + tid; i0 += PO_THREADS * PO_U) {   // uniform trip count (ballots inside)
+        PoEdge E[PO_U];
+        load_edges(i0, E);
+#pragma unroll
+        for (int u = 0; u < PO_U; u++) {
+          const PoEdge& ed = E[u];
+          const int i = i0 + u * PO_THREADS;
+          bool isbad = false;
+          if (ed.m >= 0) {
+            const bool stereo = !(ed.ur < 0);
+            double e[3], p[3];
+            // outliers: e->computeError() at the current estimate; the others keep the errors of the last computeActiveErrors
+            const float chi2 = (float)po_error(ed.outl ? est : est_err, ed.Xw, ed.x, ed.y, ed.ur, stereo, ed.info, cam, e, p);
+            isbad = chi2 > (stereo ? chi2Stereo : chi2Mono);
+            outl[i] = isbad ? 1 : 0;
+          }
+          bad += __popcll(__ballot(isbad));
         }
-        bad += __popcll(__ballot(isbad));
       }
       {
         int zero = 0;
