@@ -178,13 +178,17 @@ __device__ void se3_exp(const double* update, double* res) {
   }
 }
 
-__global__ __launch_bounds__(AL_THREADS, AL_MIN_WAVES) void k_align(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr_cur,
+// MINW = waves per SIMD the register budget is set for: 4 (128 VGPRs, four workgroups per CU: 1024 frames resident at once,
+// with spills) for large batches, 2 (256 VGPRs, fewer spills, shorter critical path) when the batch fits 512 slots anyway.
+template <int MINW>
+__global__ __launch_bounds__(AL_THREADS, MINW) void k_align(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr_cur,
                                                const uint8_t* __restrict__ pyr_ref, TrackBuffers tb, TrackCam cam,
                                                const float* __restrict__ inv_sf, const float* __restrict__ sf, int mode,
                                                int n_frames) {
   __shared__ double s_pts[AL_MAXP * 3];
   __shared__ double s_xyz[AL_MAXP * 3];
   __shared__ uint8_t s_vis[AL_MAXP + 4];
+  __shared__ __attribute__((aligned(16))) float4 s_proj[AL_MAXP];   // per point at the trial pose: {ui (< 0: not measured), vi, su, sv}
   __shared__ __attribute__((aligned(16))) float s_chi[AL_MAXP * 16];
   __shared__ double s_red[AL_WAVES][28];
   __shared__ double s_last[16], s_se3[16], s_pose[16], s_bk[16];
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(AL_THREADS, AL_MIN_WAVES) void k_align(const OrbPla
                   s_vis[pt] = 1;
                   s_xyz[pt * 3] = xc[0];
                   s_xyz[pt * 3 + 1] = xc[1];
-                  s_xyz[pt * 3 + 2] = xc[2];
+                  s_xyz[pt * 3 + 2] = invzc;   // Jacobian3DToPlane needs 1 / z only
                 }
                 const float su = u_ref - ui, sv = v_ref - vi;
                 const float w_tl = (float)((1.0 - su) * (1.0 - sv));
@@ -344,8 +348,54 @@ __global__ __launch_bounds__(AL_THREADS, AL_MIN_WAVES) void k_align(const OrbPla
         for (int i = 0; i < 16; i++) s_pose[i] = pose[i];
       }
       __syncthreads();
+      // projection of every visible point at the trial pose, once per point (its 16 pixel slots share it)
+      for (int pt = tid; pt < npts; pt += AL_THREADS) {
+        int ui = -1, vi = 0;
+        float su = 0.f, sv = 0.f;
+        if (s_vis[pt]) {
+          const double p0 = s_pts[pt * 3], p1 = s_pts[pt * 3 + 1], p2 = s_pts[pt * 3 + 2];
+          double xc[3];
+          for (int i = 0; i < 3; i++) xc[i] = (s_pose[i * 4] * p0 + s_pose[i * 4 + 1] * p1 + s_pose[i * 4 + 2] * p2) + s_pose[i * 4 + 3];
+          const double invzc = 1.0 / xc[2];
+          if (!(invzc < 0)) {
+            const double u2 = cam.fx * xc[0] * invzc + cam.cx;
+            const double v2 = cam.fy * xc[1] * invzc + cam.cy;
+            const float u_cur = (float)(u2 * scale);
+            const float v_cur = (float)(v2 * scale);
+            const int uf = (int)floorf(u_cur), vf = (int)floorf(v_cur);
+            if (!(uf < 0 || vf < 0 || uf - 3 < 0 || vf - 3 < 0 || uf + 3 >= cols || vf + 3 >= rows)) {
+              ui = uf;
+              vi = vf;
+              su = u_cur - uf;
+              sv = v_cur - vf;
+            }
+          }
+        }
+        s_proj[pt] = make_float4(__int_as_float(ui), __int_as_float(vi), su, sv);
+      }
+      __syncthreads();
       APROF(2);
       // ------------------------------------------------ ComputeResiduals
+      // all image loads of the thread's slots first (index-clamped, straight line): one round trip instead of one per slot
+      uint16_t px_top[AL_SLOTS], px_bot[AL_SLOTS];
+#pragma unroll
+      for (int k = 0; k < AL_SLOTS; k++) {
+        const int p = tid + AL_THREADS * k;
+        const int pt = p >> 4, pix = p & 15;
+        // slots without a measurement (no point, point not visible / out of the image at this pose) load from a fixed
+        // in-image address: s_proj is only written for pt < npts, and only measured points carry in-range coordinates
+        int ui = 3, vi = 3;
+        if (pt < npts) {
+          const float4 pj = s_proj[pt];
+          if (__float_as_int(pj.x) >= 0) {
+            ui = __float_as_int(pj.x);
+            vi = __float_as_int(pj.y);
+          }
+        }
+        const uint8_t* rp = img_cur + (size_t)(vi - 2 + (pix >> 2)) * step + (ui - 2 + (pix & 3));
+        __builtin_memcpy(&px_top[k], rp, 2);
+        __builtin_memcpy(&px_bot[k], rp + step, 2);
+      }
       double H[21], Jr[6];
 #pragma unroll
       for (int i = 0; i < 21; i++) H[i] = 0;
@@ -357,34 +407,25 @@ __global__ __launch_bounds__(AL_THREADS, AL_MIN_WAVES) void k_align(const OrbPla
         const int p = tid + AL_THREADS * k;
         const int pt = p >> 4, pix = p & 15;
         float chi = 0.f;
-        if (pt < npts && s_vis[pt]) {
-          const double p0 = s_pts[pt * 3], p1 = s_pts[pt * 3 + 1], p2 = s_pts[pt * 3 + 2];
-          double xc[3];
-          for (int i = 0; i < 3; i++) xc[i] = (s_pose[i * 4] * p0 + s_pose[i * 4 + 1] * p1 + s_pose[i * 4 + 2] * p2) + s_pose[i * 4 + 3];
-          const double invzc = 1.0 / xc[2];
-          if (!(invzc < 0)) {
-            const double u2 = cam.fx * xc[0] * invzc + cam.cx;
-            const double v2 = cam.fy * xc[1] * invzc + cam.cy;
-            const float u_cur = (float)(u2 * scale);
-            const float v_cur = (float)(v2 * scale);
-            const int ui = (int)floorf(u_cur), vi = (int)floorf(v_cur);
-            if (!(ui < 0 || vi < 0 || ui - 3 < 0 || vi - 3 < 0 || ui + 3 >= cols || vi + 3 >= rows)) {
-              const float su = u_cur - ui, sv = v_cur - vi;
+        if (pt < npts) {
+          const float4 pj = s_proj[pt];
+          const int ui = __float_as_int(pj.x);
+          {
+            if (ui >= 0) {
+              const float su = pj.z, sv = pj.w;
               const float w_tl = (float)((1.0 - su) * (1.0 - sv));
               const float w_tr = (float)(su * (1.0 - sv));
               const float w_bl = (float)((1.0 - su) * sv);
               const float w_br = (float)(su * sv);
-              const int y = vi - 2 + (pix >> 2), x = ui - 2 + (pix & 3);
-              const uint8_t* rp = img_cur + (size_t)y * step + x;
-              const uint8_t* rn = rp + step;
-              const float intensity = w_tl * rp[0] + w_tr * rp[1] + w_bl * rn[0] + w_br * rn[1];
+              const float intensity = w_tl * (float)(px_top[k] & 0xff) + w_tr * (float)(px_top[k] >> 8) + w_bl * (float)(px_bot[k] & 0xff) +
+                                      w_br * (float)(px_bot[k] >> 8);
               const float res = intensity - r_patch[k];
               chi = res * res * 1.0f;
               nmeas++;
               if (jvalid & (1ull << k)) {
                 // Jacobian3DToPlane at the reference-frame point, then (dx*row0 + dy*row1)*(fx*scale)
                 const double X = s_xyz[pt * 3], Y = s_xyz[pt * 3 + 1];
-                const double z_inv = 1. / s_xyz[pt * 3 + 2];
+                const double z_inv = s_xyz[pt * 3 + 2];
                 const double z_inv_2 = z_inv * z_inv;
                 double J0[6], J1[6];
                 J0[0] = -z_inv; J0[1] = 0.0; J0[2] = X * z_inv_2; J0[3] = Y * J0[2]; J0[4] = -(1.0 + X * J0[2]); J0[5] = Y * z_inv;
@@ -533,8 +574,12 @@ int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, c
                  const float* d_sf, int n_frames, int mode, hipStream_t s) {
   static const int grid_cap = [] { const char* e = getenv("SD_ALIGN_GRID"); return e ? atoi(e) : 0; }();
   const int grid = grid_cap > 0 ? std::min(n_frames, grid_cap) : n_frames;
-  hipLaunchKernelGGL(k_align, dim3(grid), dim3(AL_THREADS), 0, s, cur->d_plan, cur->d_pyr, ref->d_pyr, tb, cam, d_inv_sf, d_sf, mode,
-                     n_frames);
+  if (grid <= 512)
+    hipLaunchKernelGGL(k_align<2>, dim3(grid), dim3(AL_THREADS), 0, s, cur->d_plan, cur->d_pyr, ref->d_pyr, tb, cam, d_inv_sf, d_sf, mode,
+                       n_frames);
+  else
+    hipLaunchKernelGGL(k_align<AL_MIN_WAVES>, dim3(grid), dim3(AL_THREADS), 0, s, cur->d_plan, cur->d_pyr, ref->d_pyr, tb, cam, d_inv_sf, d_sf,
+                       mode, n_frames);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }
