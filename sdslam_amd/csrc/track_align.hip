@@ -52,6 +52,7 @@ __device__ unsigned long long g_align_prof[16];
 #define AL_WAVES (AL_THREADS / 64)
 #define AL_SLOTS ((AL_MAXP * 16 + AL_THREADS - 1) / AL_THREADS)   // pixel slots per thread
 static_assert(AL_SLOTS <= 64, "jvalid is a 64-bit mask");
+#define AL_PGROUP 10   // pixel slots whose reference-image loads are in flight together in PrecomputePatches
 
 struct Mat4 { double m[4][4]; };
 
@@ -298,44 +299,87 @@ __global__ __launch_bounds__(AL_THREADS, MINW) void k_align(const OrbPlan* __res
     for (int it = 0; it < 30; it++) {
       // ------------------------------------------------ PrecomputePatches (first iteration of a level)
       if (it == 0) {
+        // per point: projection into the reference image at this level, visibility, reference-frame coordinates
+        for (int pt = tid; pt < npts; pt += AL_THREADS) {
+          int ui = -1, vi = 0;
+          float su = 0.f, sv = 0.f;
+          const double p0 = s_pts[pt * 3], p1 = s_pts[pt * 3 + 1], p2 = s_pts[pt * 3 + 2];
+          double xc[3];
+          for (int i = 0; i < 3; i++) xc[i] = (s_last[i * 4] * p0 + s_last[i * 4 + 1] * p1 + s_last[i * 4 + 2] * p2) + s_last[i * 4 + 3];
+          const double invzc = 1.0 / xc[2];
+          if (!(invzc < 0)) {
+            const double u2 = cam.fx * xc[0] * invzc + cam.cx;
+            const double v2 = cam.fy * xc[1] * invzc + cam.cy;
+            const float u_ref = (float)(u2 * scale);
+            const float v_ref = (float)(v2 * scale);
+            const int uf = (int)floorf(u_ref), vf = (int)floorf(v_ref);
+            if (!(uf - 3 < 0 || vf - 3 < 0 || uf + 3 >= cols || vf + 3 >= rows)) {
+              s_vis[pt] = 1;
+              s_xyz[pt * 3] = xc[0];
+              s_xyz[pt * 3 + 1] = xc[1];
+              s_xyz[pt * 3 + 2] = invzc;   // Jacobian3DToPlane needs 1 / z only
+              ui = uf;
+              vi = vf;
+              su = u_ref - uf;
+              sv = v_ref - vf;
+            }
+          }
+          s_proj[pt] = make_float4(__int_as_float(ui), __int_as_float(vi), su, sv);
+        }
+        __syncthreads();
+        // per pixel slot, in two groups: all loads of the group (4 rows of the 4x4 neighbourhood: two dwords, two halfwords,
+        // index-clamped) before any is used
 #pragma unroll
-        for (int k = 0; k < AL_SLOTS; k++) {
-          const int p = tid + AL_THREADS * k;
-          const int pt = p >> 4, pix = p & 15;
-          if (pt < npts) {
-            const double p0 = s_pts[pt * 3], p1 = s_pts[pt * 3 + 1], p2 = s_pts[pt * 3 + 2];
-            double xc[3];
-            for (int i = 0; i < 3; i++) xc[i] = (s_last[i * 4] * p0 + s_last[i * 4 + 1] * p1 + s_last[i * 4 + 2] * p2) + s_last[i * 4 + 3];
-            const double invzc = 1.0 / xc[2];
-            if (!(invzc < 0)) {
-              const double u2 = cam.fx * xc[0] * invzc + cam.cx;
-              const double v2 = cam.fy * xc[1] * invzc + cam.cy;
-              const float u_ref = (float)(u2 * scale);
-              const float v_ref = (float)(v2 * scale);
-              const int ui = (int)floorf(u_ref), vi = (int)floorf(v_ref);
-              if (!(ui - 3 < 0 || vi - 3 < 0 || ui + 3 >= cols || vi + 3 >= rows)) {
-                if (pix == 0) {
-                  s_vis[pt] = 1;
-                  s_xyz[pt * 3] = xc[0];
-                  s_xyz[pt * 3 + 1] = xc[1];
-                  s_xyz[pt * 3 + 2] = invzc;   // Jacobian3DToPlane needs 1 / z only
+        for (int g0 = 0; g0 < AL_SLOTS; g0 += AL_PGROUP) {
+          uint32_t q_mid[AL_PGROUP], q_next[AL_PGROUP];
+          uint16_t q_prev[AL_PGROUP], q_next2[AL_PGROUP];
+#pragma unroll
+          for (int kk = 0; kk < AL_PGROUP; kk++) {
+            const int k = g0 + kk;
+            if (k < AL_SLOTS) {
+              const int p = tid + AL_THREADS * k;
+              const int pt = p >> 4, pix = p & 15;
+              int ui = 3, vi = 3;   // slots without a patch load from a fixed in-image address (s_proj is written for pt < npts only)
+              if (pt < npts) {
+                const float4 pj = s_proj[pt];
+                if (__float_as_int(pj.x) >= 0) {
+                  ui = __float_as_int(pj.x);
+                  vi = __float_as_int(pj.y);
                 }
-                const float su = u_ref - ui, sv = v_ref - vi;
-                const float w_tl = (float)((1.0 - su) * (1.0 - sv));
-                const float w_tr = (float)(su * (1.0 - sv));
-                const float w_bl = (float)((1.0 - su) * sv);
-                const float w_br = (float)(su * sv);
-                const int y = vi - 2 + (pix >> 2), x = ui - 2 + (pix & 3);
-                const uint8_t* rp = img_ref + (size_t)y * step + x;
-                const uint8_t* rprev = rp - step;
-                const uint8_t* rnext = rp + step;
-                const uint8_t* rnext2 = rnext + step;
-                r_patch[k] = w_tl * rp[0] + w_tr * rp[1] + w_bl * rnext[0] + w_br * rnext[1];
-                r_dx[k] = 0.5f * ((w_tl * rp[1] + w_tr * rp[2] + w_bl * rnext[1] + w_br * rnext[2]) -
-                                  (w_tl * rp[-1] + w_tr * rp[0] + w_bl * rnext[-1] + w_br * rnext[0]));
-                r_dy[k] = 0.5f * ((w_tl * rnext[0] + w_tr * rnext[1] + w_bl * rnext2[0] + w_br * rnext2[1]) -
-                                  (w_tl * rprev[0] + w_tr * rprev[1] + w_bl * rp[0] + w_br * rp[1]));
-                jvalid |= 1ull << k;
+              }
+              const uint8_t* rp = img_ref + (size_t)(vi - 2 + (pix >> 2)) * step + (ui - 2 + (pix & 3));
+              __builtin_memcpy(&q_mid[kk], rp - 1, 4);
+              __builtin_memcpy(&q_next[kk], rp + step - 1, 4);
+              __builtin_memcpy(&q_prev[kk], rp - step, 2);
+              __builtin_memcpy(&q_next2[kk], rp + 2 * (size_t)step, 2);
+            }
+          }
+#pragma unroll
+          for (int kk = 0; kk < AL_PGROUP; kk++) {
+            const int k = g0 + kk;
+            if (k < AL_SLOTS) {
+              const int p = tid + AL_THREADS * k;
+              const int pt = p >> 4;
+              if (pt < npts) {
+                const float4 pj = s_proj[pt];
+                if (__float_as_int(pj.x) >= 0) {
+                  const float su = pj.z, sv = pj.w;
+                  const float w_tl = (float)((1.0 - su) * (1.0 - sv));
+                  const float w_tr = (float)(su * (1.0 - sv));
+                  const float w_bl = (float)((1.0 - su) * sv);
+                  const float w_br = (float)(su * sv);
+                  // rp[-1..2], rnext[-1..2], rprev[0..1], rnext2[0..1]
+                  const float m_1 = (float)(q_mid[kk] & 0xff), m0 = (float)((q_mid[kk] >> 8) & 0xff), m1 = (float)((q_mid[kk] >> 16) & 0xff),
+                              m2 = (float)(q_mid[kk] >> 24);
+                  const float n_1 = (float)(q_next[kk] & 0xff), n0 = (float)((q_next[kk] >> 8) & 0xff), n1 = (float)((q_next[kk] >> 16) & 0xff),
+                              n2 = (float)(q_next[kk] >> 24);
+                  const float v0 = (float)(q_prev[kk] & 0xff), v1 = (float)(q_prev[kk] >> 8);
+                  const float x0 = (float)(q_next2[kk] & 0xff), x1 = (float)(q_next2[kk] >> 8);
+                  r_patch[k] = w_tl * m0 + w_tr * m1 + w_bl * n0 + w_br * n1;
+                  r_dx[k] = 0.5f * ((w_tl * m1 + w_tr * m2 + w_bl * n1 + w_br * n2) - (w_tl * m_1 + w_tr * m0 + w_bl * n_1 + w_br * n0));
+                  r_dy[k] = 0.5f * ((w_tl * n0 + w_tr * n1 + w_bl * x0 + w_br * x1) - (w_tl * v0 + w_tr * v1 + w_bl * m0 + w_br * m1));
+                  jvalid |= 1ull << k;
+                }
               }
             }
           }
