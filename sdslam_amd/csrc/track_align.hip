@@ -508,6 +508,32 @@ __global__ __launch_bounds__(AL_THREADS, MINW) void k_align(const OrbPlan* __res
       }
       __syncthreads();
       APROF(4);
+      // float chi2 in the reference's order (src/ImageAlign.cc:298,341): 4800 dependent adds.  Wave 0 fetches 256 terms per
+      // LDS instruction (lane l holds terms 4l .. 4l+3 of the chunk) and runs the chain THROUGH the lanes: one step is
+      // d[l] = (((d[l-1] + x[l]) + y[l]) + z[l]) + w[l] with d[l-1] taken from the neighbouring lane by DPP (wave_shr:1; lane 0
+      // takes the carry of the previous chunk).  After s steps lanes 0 .. s-1 hold their final value, so 64 steps of four
+      // dependent adds give lane 63 the chunk's sequential sum -- the same 256 adds in the same order and rounding as one
+      // lane adding them, without LDS or scalar-register latency inside the chain.  Terms of slots without a measurement
+      // are +0.0f (rewritten every iteration) and leave the sum unchanged.
+      float chi2f = 0.0f;
+      if (wave == 0) {
+        const float4* c4 = (const float4*)s_chi;
+        const int n4 = npts * 4;
+        for (int c0 = 0; c0 < n4; c0 += 64) {
+          const int idx = c0 + lane;
+          const float4 v = idx < AL_MAXP * 4 ? c4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+          float d = 0.0f;
+#pragma unroll 8
+          for (int st = 0; st < 64; st++) {
+            const float in = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(chi2f), __float_as_int(d), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+            d = in + v.x;
+            d = d + v.y;
+            d = d + v.z;
+            d = d + v.w;
+          }
+          chi2f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 63));
+        }
+      }
       // ------------------------------------------------ Optimize (serial part)
       if (tid == 0) {
         iters[level] = it + 1;
@@ -527,18 +553,6 @@ __global__ __launch_bounds__(AL_THREADS, MINW) void k_align(const OrbPlan* __res
         }
         int n_meas = 0;
         for (int w = 0; w < AL_WAVES; w++) n_meas += s_cnt[w];
-        // float chi2 in the reference's order; 16-byte LDS reads are issued ahead of the dependent adds
-        float chi2f = 0.0f;
-        const float4* c4 = (const float4*)s_chi;
-        const int n4 = npts * 4;
-#pragma unroll 8
-        for (int i = 0; i < n4; i++) {
-          const float4 v = c4[i];
-          chi2f += v.x;
-          chi2f += v.y;
-          chi2f += v.z;
-          chi2f += v.w;
-        }
         APROF(5);
         const double new_chi2 = (double)(chi2f / (float)n_meas);   // float/size_t -> float, then widened
         if (n_meas == 0) stop_ = true;
