@@ -241,11 +241,10 @@ __device__ __forceinline__ double po_error(const Se3q& T, const double* Xw, doub
   return (e[0] * (info * e[0]) + e[1] * (info * e[1])) + e[2] * (info * e[2]);
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+// sum over the wave, every lane gets the same bits (device library's DPP reduction; the order is a fixed tree, like the
+// xor-butterfly it replaces -- this stage is compared at a tolerance, see the header)
+extern "C" __device__ __attribute__((const)) double __ockl_wfred_add_f64(double);
+__device__ __forceinline__ double wave_sum(double v) { return __ockl_wfred_add_f64(v); }
 
 // One frame = one workgroup of W waves (W = 1 for large batches, where the waves of other frames fill the SIMDs and the
 // replicated scalar LM logic of extra waves would only cost; W = 4 for small batches, where the edge loops are the
