@@ -54,6 +54,9 @@ __device__ unsigned long long g_align_prof[16];
 static_assert(AL_SLOTS <= 64, "jvalid is a 64-bit mask");
 #define AL_PGROUP 10   // pixel slots whose reference-image loads are in flight together in PrecomputePatches
 
+extern "C" __device__ __attribute__((const)) double __ockl_wfred_add_f64(double);
+extern "C" __device__ __attribute__((const)) int __ockl_wfred_add_i32(int);
+
 struct Mat4 { double m[4][4]; };
 
 __device__ __forceinline__ void m4_mul(const double* a, const double* b, double* r) {   // row-major 4x4
@@ -493,14 +496,12 @@ __global__ __launch_bounds__(AL_THREADS, MINW) void k_align(const OrbPlan* __res
       }
       APROF(3);
       // fixed-shape reduction of the 27 sums + measurement count
+      // (device library's DPP reductions: a fixed tree like the shuffle butterfly they replace, every lane gets the sum)
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
+      for (int i = 0; i < 21; i++) H[i] = __ockl_wfred_add_f64(H[i]);
 #pragma unroll
-        for (int i = 0; i < 21; i++) H[i] += __shfl_xor(H[i], o);
-#pragma unroll
-        for (int i = 0; i < 6; i++) Jr[i] += __shfl_xor(Jr[i], o);
-        nmeas += __shfl_xor(nmeas, o);
-      }
+      for (int i = 0; i < 6; i++) Jr[i] = __ockl_wfred_add_f64(Jr[i]);
+      nmeas = __ockl_wfred_add_i32(nmeas);
       if (lane == 0) {
         for (int i = 0; i < 21; i++) s_red[wave][i] = H[i];
         for (int i = 0; i < 6; i++) s_red[wave][21 + i] = Jr[i];
