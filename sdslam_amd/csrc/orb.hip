@@ -515,6 +515,8 @@ __device__ unsigned long long g_fast_prof[8];
 //      re-compacted in place (still raster order) and their scores go to the LDS score map;
 //   C. after a block barrier, NMS on the queued corners against the LDS score map, then ordered
 //      emission (wave bands are contiguous in raster order, so per-wave counts give offsets).
+extern "C" __device__ __attribute__((const)) int __ockl_wfred_add_i32(int);
+
 __global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan* __restrict__ P,
                                                     const CellGeom* __restrict__ cells,
                                                     const uint8_t* __restrict__ pyr,
@@ -1028,12 +1030,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
       }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-      for (int q = 0; q < DESC_KPW; q++) {
-        m10[q] += __shfl_xor(m10[q], o);
-        m01[q] += __shfl_xor(m01[q], o);
-      }
+    for (int q = 0; q < DESC_KPW; q++) {   // integer sums: any order is exact; DPP reduction of the device library
+      m10[q] = __ockl_wfred_add_i32(m10[q]);
+      m01[q] = __ockl_wfred_add_i32(m01[q]);
     }
   }
   // ---- steered rBRIEF on the blurred level
