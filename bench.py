@@ -136,8 +136,13 @@ def pmc_for_stage(stage, batch):
     d = json.load(open(files[-1]))
     tot, valu, dur = 0.0, 0.0, 0.0
     found = False
+    def entry(name):      # templated kernels appear as "void k_align<4>"
+        for key, val in d.items():
+            if key == name or key.replace("void ", "").split("<")[0] == name:
+                return val
+        return None
     for k in STAGE_KERNELS.get(stage, []):
-        e = d.get(k)
+        e = entry(k)
         if not e or "FETCH_bytes_corrected_per_launch" not in e:
             continue
         found = True
