@@ -342,9 +342,16 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
   // (first strict minimum = smallest key), assignment (later points overwrite), rotation histogram
   int nmatches = 0, nev = 0;
   const float factor = 1.0f / HISTO_LENGTH;
-  for (int i = 0; i < n_last; i++) {
-    const uint32_t pc = s_pt[i];
-    if (pc == 0) continue;
+  // s_pt is read 64 entries at a time and only the points with something to do are visited (most slots of the arrays
+  // hold no valid point: one LDS round trip per slot was a tenth of the kernel for a single frame)
+  for (int base = 0; base < n_last; base += 64) {
+   const uint32_t pcv = (base + lane < n_last) ? s_pt[base + lane] : 0u;
+   unsigned long long todo = __ballot(pcv != 0);
+   while (todo) {
+    const int jsel = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int i = base + jsel;
+    const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)pcv, jsel);
     uint32_t best = 0x7FFFFFFFu;
     if (pc != 0xFFFFFFFFu) {
       const int off = pc >> 16, cnt = pc & 0xffff;
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
         nev++;
       }
     }
+     }
   }
   // ---- rotation consistency: keep the three dominant 30-degree bins (10 % rule)
   if (check_ori) {
@@ -628,9 +636,16 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
   if (tid >= 64) return;
   // ---- phase 2: best / second best over the unclaimed candidates, ratio test, assignment
   int nmatches = 0;
-  for (int i = 0; i < n_loc; i++) {
-    const uint32_t pc = s_pt[i];
-    if (pc == 0) continue;
+  // s_pt is read 64 entries at a time and only the points with something to do are visited (most slots of the arrays
+  // hold no valid point: one LDS round trip per slot was a tenth of the kernel for a single frame)
+  for (int base = 0; base < n_loc; base += 64) {
+   const uint32_t pcv = (base + lane < n_loc) ? s_pt[base + lane] : 0u;
+   unsigned long long todo = __ballot(pcv != 0);
+   while (todo) {
+    const int jsel = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int i = base + jsel;
+    const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)pcv, jsel);
     uint32_t gb, gs;   // the two smallest unclaimed keys of the point (wave-uniform)
     if (pc != 0xFFFFFFFFu) {
       uint32_t best = 0x7FFFFFFFu, second = 0x7FFFFFFFu;
@@ -674,6 +689,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
       if (lane == 0) s_match[bestIdx] = (int16_t)i;
       nmatches++;
     }
+     }
   }
   int32_t* out = tb.lm_match + (size_t)f * cap;
   for (int i = lane; i < cap; i += 64) out[i] = i < KP2 ? (int32_t)s_match[i] : -1;
