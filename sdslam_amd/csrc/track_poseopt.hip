@@ -213,7 +213,8 @@ struct PoCam { double fx, fy, cx, cy, bf; };
 // index-clamped loads before touching any of them: PO_U chains in flight per thread instead of one.
 constexpr int PO_U = 4;
 struct PoEdge {
-  int m;        // map point index, < 0: keypoint without map point (or beyond the keypoint count)
+  int i;        // keypoint index
+  int m;        // map point index, < 0: no edge in this slot
   int outl;     // current mvbOutlier flag
   float x, y, ur;
   double info;  // invSigma2 of the keypoint's octave
@@ -336,6 +337,10 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
   __shared__ int s_ok;
   constexpr int PO_THREADS = 64 * W;
   __shared__ PoRed<W> s_red;
+  // a thread's keypoints that carry a map point, in ascending order (its edges): [position][thread]; the edge loops walk
+  // these lists instead of all keypoints (a frame-to-frame match gives ~ a quarter of the keypoints a point)
+  constexpr int PO_SLOTS = 2048 / PO_THREADS;   // keypoint capacity of the tracker (<= 2048) / threads
+  __shared__ uint16_t s_idx[PO_SLOTS][PO_THREADS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
     __syncthreads();
@@ -356,14 +361,20 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
     const PoCam cam = {(double)tcam.ffx, (double)tcam.ffy, (double)tcam.fcx, (double)tcam.fcy, (double)tcam.bf};
     const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);   // const float delta = sqrt(..)
     const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
-    auto load_edges = [&](int i0, PoEdge (&E)[PO_U]) {
+    int my_edges = 0;   // entries of this thread's list (set below, once `match` is final)
+    auto load_edges = [&](int k0, PoEdge (&E)[PO_U]) {
       int ic[PO_U];
 #pragma unroll
       for (int u = 0; u < PO_U; u++) {
-        const int i = i0 + u * PO_THREADS;
-        ic[u] = min(i, max(nkp - 1, 0));
+        const int k = k0 + u;
+        const bool live = k < my_edges;
+        ic[u] = live ? (int)s_idx[min(k, PO_SLOTS - 1)][tid] : 0;   // slot 0 of the arrays always exists: safe dummy address
+        E[u].i = ic[u];
+      }
+#pragma unroll
+      for (int u = 0; u < PO_U; u++) {
         const int mm = match[ic[u]];
-        E[u].m = (i < nkp) ? mm : -1;
+        E[u].m = (k0 + u < my_edges) ? mm : -1;
         E[u].outl = outl[ic[u]];
       }
       int oct[PO_U];
@@ -395,11 +406,20 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
     for (int i0 = 0; i0 < nkp; i0 += PO_THREADS) {
       const int i = i0 + tid;
       const bool has = i < nkp && match[i] >= 0;
+      if (has) s_idx[my_edges++][tid] = (uint16_t)i;
       nInitial += __popcll(__ballot(has));
     }
+    int max_edges = my_edges;   // longest list of the workgroup: uniform trip count of the edge loops
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) max_edges = max(max_edges, __shfl_xor(max_edges, o));
     {
-      int zero = 0;
-      block_count2(nInitial, zero, s_red, wave, lane);
+      int neg = -max_edges;   // block_count2 sums; a maximum over waves is needed: take it from the per-wave slots below
+      block_count2(nInitial, neg, s_red, wave, lane);
+      if (W > 1) {
+        max_edges = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) max_edges = max(max_edges, -s_red.cnt[w][1]);
+      }
     }
     for (int i = tid; i < cap; i += PO_THREADS) outl[i] = 0;
     if (tid < 16) T_out[tid] = T_in[tid];
@@ -453,9 +473,9 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
         for (int k = 0; k < 21; k++) H[k] = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) b[k] = 0;
-        for (int i0 = tid; i0 < nkp; i0 += PO_THREADS * PO_U) {
+        for (int k0 = 0; k0 < max_edges; k0 += PO_U) {
          PoEdge E[PO_U];
-         load_edges(i0, E);
+         load_edges(k0, E);
 #pragma unroll
          for (int u = 0; u < PO_U; u++) {
           const PoEdge& ed = E[u];
@@ -563,9 +583,9 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
           est = se3q_mul(se3q_exp(x), est);
           // computeActiveErrors + activeRobustChi2 at the trial estimate
           double c = 0;
-          for (int i0 = tid; i0 < nkp; i0 += PO_THREADS * PO_U) {
+          for (int k0 = 0; k0 < max_edges; k0 += PO_U) {
             PoEdge E[PO_U];
-            load_edges(i0, E);
+            load_edges(k0, E);
 #pragma unroll
             for (int u = 0; u < PO_U; u++) {
               const PoEdge& ed = E[u];
@@ -617,13 +637,13 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
       rounds++;
       // ---------------- classify (src/Optimizer.cc:353-398)
       int bad = 0;
-      for (int i0 = tid; i0 < nkp + tid; i0 += PO_THREADS * PO_U) {   // uniform trip count (ballots inside)
+      for (int k0 = 0; k0 < max_edges; k0 += PO_U) {   // uniform trip count (ballots inside)
         PoEdge E[PO_U];
-        load_edges(i0, E);
+        load_edges(k0, E);
 #pragma unroll
         for (int u = 0; u < PO_U; u++) {
           const PoEdge& ed = E[u];
-          const int i = i0 + u * PO_THREADS;
+          const int i = ed.i;
           bool isbad = false;
           if (ed.m >= 0) {
             const bool stereo = !(ed.ur < 0);
