@@ -786,6 +786,51 @@ def test_degenerate_frames_through_the_whole_chain(sd, oracle):
     assert lm["in_view"][0].sum() > 500 and not lm["in_view"][1].any()      # points project into the flat frame, nothing to match
 
 
+def test_two_thousand_features_through_both_tracking_calls(sd, oracle):
+    """The tracker's capacity limits (2000 keypoints -> 2048-entry key arrays, 32 edges per PoseOptimization lane, windows
+    with more candidates than a 32-lane half at th = 30): TrackWithMotionModel and TrackLocalMap still equal the oracle."""
+    cfg = (2000, 1.2, 8, 12)
+    s = synth.make_scene(33)
+    cur, ref = sd.ORBextractor(*cfg, 640, 480, 1), sd.ORBextractor(*cfg, 640, 480, 1)
+    ck, cd, cn = cur.extract_batch(s["cur"][None])
+    rk, rd, rn = ref.extract_batch(s["ref"][None])
+    assert cn[0] == 2000 and rn[0] == 2000
+    oc, orf = oracle.OrbOracle(*cfg), oracle.OrbOracle(*cfg)
+    ock, ocd = oc.extract(s["cur"])
+    ork, ord_ = orf.extract(s["ref"])
+    assert np.array_equal(ock, ck[0, :cn[0]]) and np.array_equal(ork, rk[0, :rn[0]])
+    last = synth.tracking_case(33, ork, ord_, max_points=2000)
+    last["obs"] = (np.arange(len(last["obs"])) % 4 != 0).astype(np.int32)
+    trk = sd.Tracker(cur, ref, 2048, 1, 300)
+    trk.set_camera(*K, 0.0, BOUNDS)
+    trk.set_last(0, [last])
+    T0 = synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04)) @ s["T_cur"]
+    tab = oc.tables()
+    pc, pr = [oc.level(l) for l in range(8)], [orf.level(l) for l in range(8)]
+    n = len(ock)
+    for th in (8.0, 30.0):
+        trk.set_poses(0, [s["T_ref"]], [T0])
+        trk.align(1, 0)
+        T_al = trk.get_align(0, 1)["T"][0]
+        trk.set_poses(0, [s["T_ref"]], [T0])
+        trk.track_with_motion_model(1, th=th)
+        tw, po = trk.get_tracked(0, 1), trk.get_pose_opt(0, 1)
+        cm, _ = trk.get_matches(0, 1)
+        r = oracle.track_with_motion_model(pc, pr, tab, ock, ocd, BOUNDS, K, s["T_ref"], T0, last, th, T_aligned=T_al)
+        assert (tw["status"][0], tw["nmatches"][0], tw["nmatches_map"][0]) == (r["status"], r["nmatches"], r["nmatches_map"])
+        assert np.array_equal(cm[0, :n], r["match"]) and np.abs(po["T"][0] - r["T"]).max() <= POSE_TOL
+        assert r["status"] == 2 and r["nmatches"] > 1000
+        pts = {k: v[:2048] for k, v in synth.local_map_case(5, ock, ocd, s["T_cur"], n_extra=40).items()}
+        trk.set_local(0, [pts])
+        trk.track_local_map(1, th=1.0)
+        tl, po2, lm = trk.get_local_map(0, 1), trk.get_pose_opt(0, 1), trk.get_local(0, 1)
+        r2 = oracle.track_local_map(ock, ocd, tab, np.log(np.float32(1.2)), BOUNDS, K, po["T"][0], cm[0, :n], last, pts, th=1.0)
+        assert np.array_equal(lm["match"][0, :n], r2["local_match"]) and np.array_equal(po2["outlier"][0, :n], r2["outlier"])
+        assert (tl["status"][0], tl["n_points"][0], tl["n_inliers"][0]) == (r2["status"], r2["n_points"], r2["n_inliers"])
+        assert np.abs(po2["T"][0] - r2["T"]).max() <= POSE_TOL
+        assert r2["n_points"] > 1700
+
+
 def test_fresh_tracker_has_no_matches(sd, oracle):
     """Before any search has run the match vectors mean "no map point": PoseOptimization / TrackLocalMap called first
     find nothing to optimise instead of reading point 0 for every keypoint."""
