@@ -237,8 +237,18 @@ int sd_track_get_local_map(sd_track* h, int frame0, int n_frames, int32_t* map_m
 
 int sd_track_align(sd_track* h, int n_frames, int mode);
 int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori);
+/* sd_track_pnp = PnPsolver(CurrentFrame, CurrentFrame.mvpMapPoints) + SetRansacParameters(...) + iterate(n_iterations)
+ * (src/PnPsolver.cc:71-244); min_set 4 is the reference's default (src/PnPsolver.h:74), 1..64 are accepted.
+ * sd_track_pnp_iterate = a further iterate(n_iterations) on those solvers: mnIterations, the best hypothesis so far and the
+ * position in the rand() stream carry over (src/PnPsolver.cc:177).  Each RANSAC iteration consumes min_set values of the
+ * stream given to sd_track_set_rand; a call that could run past the supplied values fails with SD_ERR_INVALID_ARG.
+ * sd_track_set_matches replaces CurrentFrame.mvpMapPoints of the slots by the caller's vector (indices into the
+ * last-frame arrays, -1 = NULL; cap entries per frame, the rest NULL): PnPsolver and Optimizer::PoseOptimization take any
+ * match vector, not only the one sd_track_match leaves (src/PnPsolver.cc:71-110, src/Optimizer.cc:240-330). */
 int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers, int max_iterations,
                  int min_set, float epsilon, float th2, int n_iterations);
+int sd_track_pnp_iterate(sd_track* h, int n_frames, int n_iterations);
+int sd_track_set_matches(sd_track* h, int frame0, int n_frames, const int32_t* cur_match, int cap);
 
 /* sd_track_set_poses: LastFrame.GetPose() and the current frame's prior pose (motion-model
  * prediction); sd_track_align reads the prior and leaves the aligned pose for the later stages.

@@ -25,7 +25,9 @@ _libs = {}
 def lib(fast: bool = False):
     if fast not in _libs:
         path = os.path.join(_HERE, "build", "liboracle_fast.so" if fast else "liboracle.so")
-        if not os.path.exists(path):
+        if os.environ.get("SD_ORACLE_LIB"):      # the sanitizer build (make -C oracle asan), tests/test_oracle_asan.py
+            path = os.environ["SD_ORACLE_LIB"]
+        elif not os.path.exists(path):
             build(fast)
         L = C.CDLL(path)
         L.orc_orb_create.restype = C.c_void_p
@@ -322,6 +324,19 @@ def features_in_area(kps_un, bounds, x, y, r, min_level=-1, max_level=-1):
     n = L.orc_features_in_area(len(kps_un), _p(kps_un), *[float(b) for b in bounds], float(x), float(y), float(r),
                                min_level, max_level, _p(out), len(out))
     return out[:n].copy()
+
+
+def search_by_points(kps_un1, desc1, has_mp1, kps_un2, desc2, has_mp2, nnratio=0.75, check_ori=True):
+    """ORBmatcher::SearchByPoints(currentKF, pKF, matches) -> (nmatches, matches12[N1] = pKF keypoint index or -1)."""
+    L = lib()
+    k1, k2 = np.ascontiguousarray(kps_un1), np.ascontiguousarray(kps_un2)
+    d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+    h1, h2 = np.ascontiguousarray(has_mp1, np.uint8), np.ascontiguousarray(has_mp2, np.uint8)
+    m = np.zeros(len(k1), np.int32)
+    L.orc_search_by_points.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_float, C.c_int, C.c_void_p]
+    n = L.orc_search_by_points(len(k1), _p(k1), _p(d1), _p(h1), len(k2), _p(k2), _p(d2), _p(h2), float(nnratio), int(check_ori), _p(m))
+    return n, m
 
 
 def descriptor_distance(a, b):

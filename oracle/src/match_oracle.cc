@@ -6,6 +6,7 @@
 //   ORBmatcher::DescriptorDistance            src/ORBmatcher.cc:1459-1473
 //   ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)   src/ORBmatcher.cc:946-1075
 //   ORBmatcher::ComputeThreeMaxima            src/ORBmatcher.cc:1423-1454
+//   ORBmatcher::SearchByPoints(KeyFrame*, KeyFrame*, matches)         src/ORBmatcher.cc:1209-1301 (brute-force Hamming)
 // MapPoint pointers are flattened to indices into the last frame's arrays: cur_match[i2] = index
 // of the last-frame map point assigned to current keypoint i2, or -1 (NULL).
 // Quirks kept: histogram factor 1/30, PosInGrid rounds while
@@ -21,7 +22,7 @@ namespace orc {
 struct KeyPoint { float x, y, size, angle, response; int32_t octave, class_id; };
 
 static const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;   // src/Frame.h:34-35
-static const int TH_HIGH = 100, HISTO_LENGTH = 30;             // src/ORBmatcher.cc:36-38
+static const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;   // src/ORBmatcher.cc:36-38
 
 static int DescriptorDistance(const uint8_t* a, const uint8_t* b) {
   const int32_t* pa = (const int32_t*)a;
@@ -214,6 +215,66 @@ int orc_search_by_projection(int N, const void* keysUn_, const uint8_t* desc, co
 }
 
 int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
+
+// ORBmatcher::SearchByPoints(currentKF, pKF, matches) (src/ORBmatcher.cc:1209-1301): brute-force Hamming over the map
+// points of two keyframes.  has_mp1 / has_mp2 = "GetMapPointMatches()[i] != NULL && !isBad()"; matches12[idx1] = index of
+// the pKF keypoint whose map point is assigned (the reference stores vpMapPoints2[bestIdx2]) or -1.
+int orc_search_by_points(int N1, const void* keysUn1_, const uint8_t* desc1, const uint8_t* has_mp1, int N2, const void* keysUn2_,
+                         const uint8_t* desc2, const uint8_t* has_mp2, float mfNNratio, int mbCheckOrientation, int* matches12) {
+  const KeyPoint* vKeysUn1 = (const KeyPoint*)keysUn1_;
+  const KeyPoint* vKeysUn2 = (const KeyPoint*)keysUn2_;
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int i = 0; i < N1; i++) matches12[i] = -1;
+  std::vector<bool> vbMatched2(N2, false);
+  for (int idx1 = 0; idx1 < N1; idx1++) {
+    if (!has_mp1[idx1]) continue;
+    const uint8_t* d1 = desc1 + (size_t)idx1 * 32;
+    int bestDist1 = 256;
+    int bestIdx2 = -1;
+    int bestDist2 = 256;
+    for (int idx2 = 0; idx2 < N2; idx2++) {
+      if (!has_mp2[idx2] || vbMatched2[idx2]) continue;
+      const uint8_t* d2 = desc2 + (size_t)idx2 * 32;
+      int dist = DescriptorDistance(d1, d2);
+      if (dist < bestDist1) {
+        bestDist2 = bestDist1;
+        bestDist1 = dist;
+        bestIdx2 = idx2;
+      } else if (dist < bestDist2) {
+        bestDist2 = dist;
+      }
+    }
+    if (bestDist1 < TH_LOW) {
+      if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+        matches12[idx1] = bestIdx2;
+        vbMatched2[bestIdx2] = true;
+        if (mbCheckOrientation) {
+          float rot = vKeysUn1[idx1].angle - vKeysUn2[bestIdx2].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin].push_back(idx1);
+        }
+        nmatches++;
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        matches12[rotHist[i][j]] = -1;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
 
 // Frame::UndistortKeyPoints (reference src/Frame.cc:335-366): cv::undistortPoints(pts, pts, K, dist, Mat(), K)
 // restated from OpenCV 3.2 cvUndistortPoints (5 fixed-point iterations, fp64 inside, f32 in/out;

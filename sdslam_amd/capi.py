@@ -522,6 +522,18 @@ class Tracker:
         _check(self.L.sd_track_pnp(self.h, n_frames, probability, min_inliers, max_iterations, min_set, epsilon, th2,
                                    n_iterations))
 
+    def pnp_iterate(self, n_frames, n_iterations):
+        """A further PnPsolver::iterate(n_iterations) on the solvers the last pnp() call constructed."""
+        self.L.sd_track_pnp_iterate.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _check(self.L.sd_track_pnp_iterate(self.h, n_frames, int(n_iterations)))
+
+    def set_matches(self, frame0, cur_match):
+        """CurrentFrame.mvpMapPoints of the slots from the caller: [n, cap'] indices into the last-frame arrays, -1 = NULL."""
+        m = np.ascontiguousarray(cur_match, np.int32)
+        assert m.ndim == 2
+        self.L.sd_track_set_matches.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _check(self.L.sd_track_set_matches(self.h, frame0, m.shape[0], _p(m), m.shape[1]))
+
     def get_align(self, frame0, n):
         T = np.zeros((n, 16))
         err = np.zeros(n)

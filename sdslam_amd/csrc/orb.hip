@@ -1167,26 +1167,15 @@ static int wait_trackers(sd_orb* h) {   // host-side: nothing may still read any
 
 static void drop_graphs(sd_orb* h);
 
-static int ensure_geometry(sd_orb* h, int w, int hgt) {
-  if (h->have_geom && h->cur_w == w && h->cur_h == hgt) return SD_OK;
-  SD_REQUIRE(w <= h->max_w && hgt <= h->max_h, SD_ERR_CAPACITY, "frame larger than the handle's max_w x max_h");
-  const char* why = "";
-  if (!plan_geometry(h->nfeatures, h->nlevels, h->thFAST, w, hgt, h->hp, &why)) {
-    set_error(std::string("unsupported geometry: ") + why);
-    return SD_ERR_INVALID_ARG;
-  }
-  SD_REQUIRE(h->hp.max_cells_per_level <= SEL_MAX_CELLS, SD_ERR_INVALID_ARG, "too many grid cells per level");
-  SD_HIP_CHECK(hipSetDevice(h->device));
-  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
-  { int rcw = wait_trackers(h); if (rcw != SD_OK) return rcw; }
-  drop_graphs(h);
-  free_geom(h);
-  const HostPlan& hp = h->hp;
+// Geometry (re)build.  Everything that can fail -- planning, allocation, upload -- works on a LOCAL plan and the handle is
+// marked "no geometry" first, so a failure (a frame too small to plan, an allocation that does not fit) leaves a handle
+// that rebuilds from scratch on its next call instead of one whose host plan no longer matches its device buffers.
+static int build_geometry(sd_orb* h, const HostPlan& hp) {
   const size_t B = h->max_batch;
   const size_t slack = 4096;
   SD_HIP_CHECK(hipMalloc(&h->d_cells, std::max<size_t>(hp.cells.size(), 1) * sizeof(CellGeom)));
   SD_HIP_CHECK(hipMalloc(&h->d_tiles, std::max<size_t>(hp.blur_tiles.size(), 1) * sizeof(BlurTile)));
-  SD_HIP_CHECK(hipMalloc(&h->d_coef, hp.coef.size() * sizeof(int32_t)));
+  SD_HIP_CHECK(hipMalloc(&h->d_coef, std::max<size_t>(hp.coef.size(), 1) * sizeof(int32_t)));
   for (int i = 0; i < h->nsets; i++) {
     SD_HIP_CHECK(hipMalloc(&h->pyr_set[i], hp.plan.pyr_frame_bytes * B + slack));
     SD_HIP_CHECK(hipMemsetAsync(h->pyr_set[i], 0, hp.plan.pyr_frame_bytes * B + slack, h->stream));
@@ -1203,9 +1192,37 @@ static int ensure_geometry(sd_orb* h, int w, int hgt) {
     SD_HIP_CHECK(hipMemcpyAsync(h->d_cells, hp.cells.data(), hp.cells.size() * sizeof(CellGeom), hipMemcpyHostToDevice, h->stream));
   if (!hp.blur_tiles.empty())
     SD_HIP_CHECK(hipMemcpyAsync(h->d_tiles, hp.blur_tiles.data(), hp.blur_tiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice, h->stream));
-  SD_HIP_CHECK(hipMemcpyAsync(h->d_coef, hp.coef.data(), hp.coef.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  if (!hp.coef.empty())
+    SD_HIP_CHECK(hipMemcpyAsync(h->d_coef, hp.coef.data(), hp.coef.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   SD_HIP_CHECK(hipMemcpyAsync(h->d_plan, &hp.plan, sizeof(OrbPlan), hipMemcpyHostToDevice, h->stream));
   SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SD_OK;
+}
+
+static int ensure_geometry(sd_orb* h, int w, int hgt) {
+  if (h->have_geom && h->cur_w == w && h->cur_h == hgt) return SD_OK;
+  SD_REQUIRE(w <= h->max_w && hgt <= h->max_h, SD_ERR_CAPACITY, "frame larger than the handle's max_w x max_h");
+  const char* why = "";
+  HostPlan np = h->hp;   // carries the size-independent tables (scale factors, quotas, umax, pattern)
+  if (!plan_geometry(h->nfeatures, h->nlevels, h->thFAST, w, hgt, np, &why)) {
+    set_error(std::string("unsupported geometry: ") + why);
+    return SD_ERR_INVALID_ARG;   // the handle keeps its previous, still consistent geometry
+  }
+  SD_REQUIRE(np.max_cells_per_level <= SEL_MAX_CELLS, SD_ERR_INVALID_ARG, "too many grid cells per level");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  SD_HIP_CHECK(hipStreamSynchronize(h->stream));
+  { int rcw = wait_trackers(h); if (rcw != SD_OK) return rcw; }
+  drop_graphs(h);
+  h->have_geom = false;
+  h->cur_w = h->cur_h = 0;
+  h->last_frames = 0;
+  free_geom(h);
+  const int rc = build_geometry(h, np);
+  if (rc != SD_OK) {
+    free_geom(h);   // partial allocations; have_geom stays false: the next call rebuilds everything
+    return rc;
+  }
+  h->hp = std::move(np);
   h->have_geom = true;
   h->cur_w = w;
   h->cur_h = hgt;
@@ -1351,6 +1368,8 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
     if (rc == SD_OK) SD_HIP_CHECK(hipGraphLaunch(ge->exec, s));
   }
   if (rc != SD_OK) return rc;
+  // inside a captured graph ev_pyr_done is a graph node, not an event record a later hipStreamWaitEvent could see
+  h->pyr_event_live = prof || !use_graph;
   SD_HIP_CHECK(hipEventRecord(h->ev_extract_done, s));
   h->extract_recorded = true;
   if (prof) h->ev_calls++;

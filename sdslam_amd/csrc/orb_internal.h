@@ -40,6 +40,7 @@ struct sd_orb {
   bool set_busy[2] = {false, false};
   hipEvent_t ev_extract_done = nullptr;   // end of the most recent extraction on `stream`
   bool extract_recorded = false;
+  bool pyr_event_live = false;            // ev_pyr_done of the most recent extraction is a real record (not a captured graph node)
   // device buffers
   sd::OrbPlan* d_plan = nullptr;
   sd::CellGeom* d_cells = nullptr;

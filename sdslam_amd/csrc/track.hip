@@ -28,6 +28,10 @@ struct sd_track {
   sd_orb* ref = nullptr;
   int max_points = 0, max_batch = 0, kp_cap = 0, device = 0;
   int rand_per_frame = 0;
+  std::vector<int> rand_len;      // rand() values actually supplied per slot (sd_track_set_rand)
+  bool have_pnp = false;          // sd_track_pnp has constructed the solvers sd_track_pnp_iterate continues
+  PnpParams pnp_params{};
+  int pnp_frames = 0, pnp_iter_upper = 0;   // slots / upper bound of mnIterations of those solvers
   TrackBuffers tb{};
   TrackCam cam{};
   bool have_cam = false;
@@ -83,6 +87,7 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   h->kp_cap = nsel;
   h->device = cur->device;
   h->rand_per_frame = 4 * pnp_max_iterations;
+  h->rand_len.assign((size_t)max_batch, 0);
   const size_t B = max_batch, M = max_points, K = nsel;
   TrackBuffers& tb = h->tb;
   tb.max_points = max_points;
@@ -115,6 +120,9 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.pnp_scratch, B * K * 12));
   A(dalloc(h, &tb.pnp_pts, B * K * 6));
   A(dalloc(h, &tb.pnp_kpidx, B * K));
+  A(dalloc(h, &tb.pnp_state, B * 4));
+  A(dalloc(h, &tb.pnp_best_mask, B * 32));
+  A(dalloc(h, &tb.pnp_best_T, B * 12));
   A(dalloc(h, &tb.lm_cand, B * M));
   A(dalloc(h, &tb.lm_Xw, B * M * 3));
   A(dalloc(h, &tb.lm_normal, B * M * 3));
@@ -243,6 +251,11 @@ int sd_track_set_last(sd_track* h, int frame0, int n_frames, const int32_t* n_la
   SD_REQUIRE(n_last && valid && Xw && desc && octave && angle && obs, SD_ERR_INVALID_ARG, "NULL argument");
   const size_t M = h->max_points, o = (size_t)frame0;
   for (int f = 0; f < n_frames; f++) SD_REQUIRE(n_last[f] >= 0 && n_last[f] <= h->max_points, SD_ERR_CAPACITY, "n_last exceeds max_points");
+  // the octave indexes mvScaleFactors / mvLevelSigma2 on the device (search radius, level window)
+  for (int f = 0; f < n_frames; f++)
+    for (int i = 0; i < n_last[f]; i++)
+      SD_REQUIRE(!valid[(size_t)f * M + i] || (octave[(size_t)f * M + i] >= 0 && octave[(size_t)f * M + i] < h->cur->nlevels),
+                 SD_ERR_INVALID_ARG, "octave of a valid last-frame point outside [0, nlevels)");
   hipStream_t s = h->cur->stream;
   const TrackBuffers& tb = h->tb;
   SD_HIP_CHECK(hipMemcpyAsync(tb.n_last + o, n_last, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
@@ -273,6 +286,7 @@ int sd_track_set_rand(sd_track* h, int frame0, int n_frames, const int32_t* rand
   SD_HIP_CHECK(hipMemcpy2DAsync(h->tb.rand_stream + (size_t)frame0 * h->rand_per_frame, (size_t)h->rand_per_frame * 4, rand_values,
                                 (size_t)per_frame * 4, (size_t)per_frame * 4, n_frames, hipMemcpyHostToDevice, h->cur->stream));
   SD_HIP_CHECK(hipStreamSynchronize(h->cur->stream));
+  for (int f = 0; f < n_frames; f++) h->rand_len[(size_t)frame0 + f] = per_frame;
   return SD_OK;
 }
 
@@ -282,7 +296,7 @@ static int wait_inputs(sd_track* h, bool need_ref, bool pyramid_only = false) {
   // descriptors of the same batch (SD_ALIGN_EARLY=0 restores the wait for the whole extraction)
   static const bool early = !(getenv("SD_ALIGN_EARLY") && getenv("SD_ALIGN_EARLY")[0] == '0');
   if (h->cur->extract_recorded)
-    SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, (pyramid_only && early) ? h->cur->ev_pyr_done : h->cur->ev_extract_done, 0));
+    SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, (pyramid_only && early && h->cur->pyr_event_live) ? h->cur->ev_pyr_done : h->cur->ev_extract_done, 0));
   if (need_ref && h->ref->extract_recorded) SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, h->ref->ev_extract_done, 0));
   return SD_OK;
 }
@@ -666,13 +680,59 @@ int sd_track_get_stereo(sd_track* h, int frame0, int n_frames, float* uright, fl
   return SD_OK;
 }
 
+// PnPsolver(F, vpMapPointMatches) accepts ANY match vector (reference src/PnPsolver.cc:71-110), and so does
+// Optimizer::PoseOptimization through pFrame->mvpMapPoints: this replaces the slot's CurrentFrame.mvpMapPoints (indices into
+// the last-frame arrays, -1 = NULL) with the caller's, as if a search had produced them.
+int sd_track_set_matches(sd_track* h, int frame0, int n_frames, const int32_t* cur_match, int cap) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(cur_match && cap >= 1 && cap <= h->kp_cap, SD_ERR_INVALID_ARG, "bad match array (cap must be 1..keypoint capacity)");
+  std::vector<int32_t> full((size_t)n_frames * h->kp_cap, -1), cnt((size_t)n_frames, 0);
+  for (int f = 0; f < n_frames; f++)
+    for (int i = 0; i < cap; i++) {
+      const int32_t m = cur_match[(size_t)f * cap + i];
+      SD_REQUIRE(m >= -1 && m < h->max_points, SD_ERR_INVALID_ARG, "match index outside [-1, max_points)");
+      full[(size_t)f * h->kp_cap + i] = m;
+      cnt[f] += m >= 0;
+    }
+  hipStream_t s = h->cur->stream;
+  SD_HIP_CHECK(hipMemcpyAsync(h->tb.cur_match + (size_t)frame0 * h->kp_cap, full.data(), full.size() * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(h->tb.n_matches + frame0, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
+}
+
+static int run_pnp(sd_track* h, int n_frames, const PnpParams& pp) {
+  hipStream_t s = h->pnp_stream;
+  int rc = wait_inputs(h, false);
+  if (rc != SD_OK) return rc;
+  hipEvent_t* ev = h->ev[h->ev_calls[2] % sd_track::kRing];
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[4], s));
+  rc = launch_pnp(h->cur, h->tb, h->cam, h->d_sigma2, pp, n_frames, s);
+  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[5], s)); h->ev_calls[2]++; }
+  if (rc == SD_OK) rc = mark_reads(h, false);
+  return rc;
+}
+
+// every slot must have been given the rand() values the call can consume: minSet per RANSAC iteration
+static int check_rand(sd_track* h, int n_frames, long long need) {
+  SD_REQUIRE(need <= h->rand_per_frame, SD_ERR_CAPACITY, "iterations exceed the handle's pnp_max_iterations (x4 rand values per slot)");
+  for (int f = 0; f < n_frames; f++)
+    SD_REQUIRE(h->rand_len[f] >= need, SD_ERR_INVALID_ARG,
+               "sd_track_set_rand supplied fewer rand() values than the iterations can consume (minSet per iteration)");
+  return SD_OK;
+}
+
+// PnPsolver ctor + SetRansacParameters + iterate(n_iterations) (reference src/PnPsolver.cc:71-244)
 int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers, int max_iterations, int min_set, float epsilon,
                  float th2, int n_iterations) {
   int rc = check_ready(h, n_frames);
   if (rc != SD_OK) return rc;
-  SD_REQUIRE(min_set == 4, SD_ERR_INVALID_ARG, "minSet must be 4 (EPnP minimal set)");
-  SD_REQUIRE(max_iterations >= 1 && 4 * std::max(max_iterations, n_iterations) <= h->rand_per_frame, SD_ERR_CAPACITY,
-             "iterations exceed the handle's pnp_max_iterations");
+  // the reference's default is 4 (src/PnPsolver.h:74); other sizes go through the general (one hypothesis at a time) path
+  SD_REQUIRE(min_set >= 1 && min_set <= 64, SD_ERR_INVALID_ARG, "minSet must be in [1, 64]");
+  SD_REQUIRE(max_iterations >= 1 && n_iterations >= 0 && min_inliers >= 0, SD_ERR_INVALID_ARG, "bad RANSAC parameters");
+  const long long upper = std::max(max_iterations, n_iterations);
+  rc = check_rand(h, n_frames, (long long)min_set * upper);
+  if (rc != SD_OK) return rc;
   PnpParams pp;
   pp.probability = probability;
   pp.min_inliers = min_inliers;
@@ -682,14 +742,34 @@ int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers,
   pp.th2 = th2;
   pp.n_iterations = n_iterations;
   pp.rand_per_frame = h->rand_per_frame;
-  hipStream_t s = h->pnp_stream;
-  rc = wait_inputs(h, false);
+  pp.resume = 0;
+  rc = run_pnp(h, n_frames, pp);
+  if (rc == SD_OK) {
+    h->have_pnp = true;
+    h->pnp_params = pp;
+    h->pnp_frames = n_frames;
+    h->pnp_iter_upper = (int)upper;
+  }
+  return rc;
+}
+
+// A further PnPsolver::iterate(n_iterations) on the solvers the last sd_track_pnp constructed: mnIterations, the best
+// hypothesis so far and the position in the rand() stream carry over (src/PnPsolver.cc:177: the loop runs while
+// mnIterations < mRansacMaxIts OR nCurrentIterations < nIterations, so after the first call every call adds exactly
+// n_iterations).  The match vector must not have been changed in between (the reference's solver holds its own copy).
+int sd_track_pnp_iterate(sd_track* h, int n_frames, int n_iterations) {
+  int rc = check_ready(h, n_frames);
   if (rc != SD_OK) return rc;
-  hipEvent_t* ev = h->ev[h->ev_calls[2] % sd_track::kRing];
-  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[4], s));
-  rc = launch_pnp(h->cur, h->tb, h->cam, h->d_sigma2, pp, n_frames, s);
-  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[5], s)); h->ev_calls[2]++; }
-  if (rc == SD_OK) rc = mark_reads(h, false);
+  SD_REQUIRE(h->have_pnp && n_frames <= h->pnp_frames, SD_ERR_INVALID_ARG, "sd_track_pnp has not constructed solvers for these slots");
+  SD_REQUIRE(n_iterations >= 0, SD_ERR_INVALID_ARG, "bad n_iterations");
+  PnpParams pp = h->pnp_params;
+  const long long upper = std::max<long long>(pp.max_iterations, (long long)h->pnp_iter_upper + n_iterations);
+  rc = check_rand(h, n_frames, (long long)pp.min_set * upper);
+  if (rc != SD_OK) return rc;
+  pp.n_iterations = n_iterations;
+  pp.resume = 1;
+  rc = run_pnp(h, n_frames, pp);
+  if (rc == SD_OK) h->pnp_iter_upper = (int)upper;
   return rc;
 }
 

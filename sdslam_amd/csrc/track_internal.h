@@ -43,6 +43,10 @@ struct TrackBuffers {
   double* pnp_scratch;   // [B][kp_cap*12] EPnP per-correspondence work arrays (pws, us, alphas, pcs)
   float* pnp_pts;        // [B][kp_cap][6] gathered correspondences {u, v, X, Y, Z, maxErr}
   uint16_t* pnp_kpidx;   // [B][kp_cap] mvKeyPointIndices
+  // PnPsolver members that persist between iterate() calls (sd_track_pnp constructs, sd_track_pnp_iterate continues)
+  int32_t* pnp_state;    // [B][4]: mnIterations, mnBestInliers, Refine() outcome for the current best set, 0
+  unsigned long long* pnp_best_mask;   // [B][32] mvbBestInliers as bits over the gathered correspondences
+  float* pnp_best_T;     // [B][12] mBestTcw (R row-major, t)
   // local map (TrackLocalMap's search); capacity M like the last-frame arrays
   uint8_t* lm_cand;      // [B][M]   point reaches isInFrustum (not bad, not already seen in this frame)
   double* lm_Xw;         // [B][M][3]
@@ -86,6 +90,7 @@ struct PnpParams {
   float epsilon, th2;
   int n_iterations;     // argument of iterate()
   int rand_per_frame;   // entries of rand_stream per frame
+  int resume;           // 0: freshly constructed solver; 1: a further iterate() on the state the last call left
 };
 
 int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sf,

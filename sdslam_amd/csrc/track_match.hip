@@ -21,6 +21,8 @@
 // the undistorted ones (Frame::mvKeysUn).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "orb_internal.h"
 #include "track_internal.h"
 
@@ -181,7 +183,9 @@ __device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __rest
 
 // Dynamic LDS layout (KP2 = power of two >= keypoint capacity, MP = max_points):
 //   u32 s_key[KP2] | u32 s_list[MT_LIST_CAP] | u32 s_pt[MP] | f32 s_kang[KP2] | u32 s_obs[(MP+31)/32] | u32 s_valid[(MP+31)/32] |
-//   i16 s_match[KP2] | u16 s_ev[KP2] | u16 s_cstart[64*48+2] | int s_hist[30] | int s_nlist
+//   i16 s_match[KP2] | u16 s_ev[max(KP2, MP)] | u16 s_cstart[64*48+2] | int s_hist[30] | int s_nlist
+// (s_ev records one entry per ASSIGNMENT -- rotHist[bin].push_back -- and a keypoint may be assigned again by a later
+// point, so up to n_last <= MP entries: it is sized by the larger of the two capacities)
 __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
                                                           const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
                                                           const float* __restrict__ sf, float th, int mono, int check_ori, int KP2,
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
   uint32_t* s_valid = s_obs + ((MP + 31) >> 5);
   int16_t* s_match = (int16_t*)(s_valid + ((MP + 31) >> 5));
   uint16_t* s_ev = (uint16_t*)(s_match + KP2);
-  uint16_t* s_cstart = s_ev + KP2;
+  uint16_t* s_cstart = s_ev + (KP2 > MP ? KP2 : MP);
   int* s_hist = (int*)(((uintptr_t)(s_cstart + GRID_COLS * GRID_ROWS + 2) + 3) & ~(uintptr_t)3);
   int* s_nlist = s_hist + HISTO_LENGTH;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = 64 * MT_WAVES;
@@ -748,7 +752,7 @@ int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam,
   SD_REQUIRE(KP2 <= MT_MAXKP && tb.max_points <= 2048, SD_ERR_CAPACITY, "matcher supports at most 2048 keypoints / map points per frame");
   const int MP = tb.max_points;
   const size_t lds = (size_t)KP2 * 4 + MT_LIST_CAP * 4 + (size_t)MP * 4 + (size_t)KP2 * 4 + (size_t)((MP + 31) >> 5) * 8 + (size_t)KP2 * 2 +
-                     (size_t)KP2 * 2 + (GRID_COLS * GRID_ROWS + 2) * 2 + 4 + (HISTO_LENGTH + 1) * 4;
+                     (size_t)std::max(KP2, MP) * 2 + (GRID_COLS * GRID_ROWS + 2) * 2 + 4 + (HISTO_LENGTH + 1) * 4;
   hipLaunchKernelGGL(k_match, dim3(n_frames), dim3(64 * MT_WAVES), lds, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_desc,
                      cur->d_nout, tb, cam, d_sf, th, mono, check_ori, KP2, retry_below);
   SD_HIP_CHECK(hipGetLastError());

@@ -25,10 +25,11 @@
 
 namespace sd {
 
-#define PNP_MAXN 1024
+#define PNP_MAXN 2048   // = the tracker's keypoint capacity limit (sd_track_create)
 #define PNP_CHUNK 8    // RANSAC hypotheses evaluated side by side (typical runs accept within the first few);
                        // 3 lanes per hypothesis (one per EPnP beta variant)
 #define PNP_WORDS (PNP_MAXN / 64)
+#define PNP_MAXSET 64   // largest RANSAC minimal set (mRansacMinSet) the general path draws
 
 // Lane-interleaved LDS array: element i of this lane lives at p[i * PNP_CHUNK], so the
 // PNP_CHUNK lanes that solve hypotheses side by side hit distinct banks.  The big per-lane EPnP
@@ -1049,6 +1050,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
   __shared__ int s_cnt[PNP_CHUNK];
   __shared__ double s_RtRef[12];
   __shared__ double s_mtm[144], s_terms[64 * 9], s_red[64];
+  __shared__ int s_modp[PNP_MAXSET], s_modv[PNP_MAXSET], s_draw[PNP_MAXSET];   // general minimal sets (mRansacMinSet != 4)
   const int lane = threadIdx.x;
   // persistent waves: the grid may be smaller than the batch (launch_pnp)
   for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
@@ -1117,23 +1119,48 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
     info[0] = 0; info[1] = 0; info[2] = 0; info[3] = 0; info[4] = N; info[5] = minInl; info[6] = maxIts; info[7] = 0;
     for (int i = 0; i < 16; i++) T_out[i] = 0.f;
   }
+  if (!pp.resume && lane == 0) {   // a freshly constructed solver
+    tb.pnp_state[(size_t)f * 4] = 0;
+    tb.pnp_state[(size_t)f * 4 + 1] = 0;
+    tb.pnp_state[(size_t)f * 4 + 2] = 0;
+  }
   if (N < minInl) {
-    if (lane == 0) info[2] = 1;   // bNoMore
+    if (lane == 0) {
+      info[2] = 1;   // bNoMore
+      info[3] = pp.resume ? tb.pnp_state[(size_t)f * 4] : 0;
+    }
     continue;
   }
-  const int total = max(maxIts, pp.n_iterations);   // while (mnIterations < maxIts || nCurrent < nIterations)
+  // ---- solver state that outlives an iterate() call (src/PnPsolver.h: mnIterations, mnBestInliers, mvbBestInliers,
+  // mBestTcw); refine_ok = what Refine() returns for the CURRENT best set (it is a pure function of that set)
+  int32_t* st = tb.pnp_state + (size_t)f * 4;
+  unsigned long long* st_mask = tb.pnp_best_mask + (size_t)f * PNP_WORDS;
+  float* st_T = tb.pnp_best_T + (size_t)f * 12;
   const int nwords = (N + 63) >> 6;
-  const int32_t* rs = tb.rand_stream + (size_t)f * pp.rand_per_frame;
-  int best = 0, accepted = 0, acc_iters = 0, acc_cnt = 0;
+  int start = 0, best = 0, refine_ok = 0;
   float bestT[12];
   for (int i = 0; i < 12; i++) bestT[i] = 0.f;
+  if (pp.resume) {
+    start = st[0];
+    best = st[1];
+    refine_ok = st[2];
+    for (int i = 0; i < 12; i++) bestT[i] = st_T[i];
+    for (int w = lane; w < nwords; w += 64) s_best[w] = st_mask[w];
+  }
+  // while (mnIterations < mRansacMaxIts || nCurrentIterations < nIterations)
+  const int total = max(maxIts, start + pp.n_iterations);
+  const int32_t* rs = tb.rand_stream + (size_t)f * pp.rand_per_frame;
+  int accepted = 0, acc_iters = 0, acc_cnt = 0;
   double* scratch = tb.pnp_scratch + (size_t)f * cap * 12;
+  const int mset = pp.min_set;
+  const int chunk = mset == 4 ? PNP_CHUNK : 1;
+  __syncthreads();
 
-  for (int c0 = 0; c0 < total; c0 += PNP_CHUNK) {
+  for (int c0 = start; c0 < total; c0 += chunk) {
     PROF(11);
-    const int it = c0 + hyp;
-    const int nact = min(PNP_CHUNK, total - c0);
-    {
+    const int nact = min(chunk, total - c0);
+    if (mset == 4) {
+      const int it = c0 + hyp;
       const bool active = lane < 3 * PNP_CHUNK && hyp < nact;
       // minimal set: 4 draws without replacement from mvAllIndices via swap-with-back removal
       int modp[4], modv[4], nmod = 0, size = N;
@@ -1171,6 +1198,43 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
         for (int i = 0; i < 9; i++) s_Rt[hyp][i] = R[i / 3][i % 3];
         for (int i = 0; i < 3; i++) s_Rt[hyp][9 + i] = t[i];
       }
+    } else {
+      // general minimal set (mRansacMinSet != 4; the reference only ever constructs 4, src/PnPsolver.h:74, but the setter takes
+      // any): one hypothesis at a time through the wave-cooperative solver the refit uses.  The draws are the serial
+      // swap-with-back removal of src/PnPsolver.cc:185-194 on lane 0 (list of modified positions instead of the N-entry copy).
+      if (lane == 0) {
+        int size = N, nmod = 0;
+        for (int k = 0; k < mset; k++) {
+          const int ridx = mset * c0 + k;
+          const int r = ridx < pp.rand_per_frame ? rs[ridx] : 0;
+          const int randi = (int)(((double)r / (2147483647.0 + 1.0)) * size + 0);
+          int val = randi, backv = size - 1;
+          for (int q = 0; q < nmod; q++) {
+            if (s_modp[q] == randi) val = s_modv[q];
+            if (s_modp[q] == size - 1) backv = s_modv[q];
+          }
+          bool found = false;
+          for (int q = 0; q < nmod; q++)
+            if (s_modp[q] == randi) { s_modv[q] = backv; found = true; }
+          if (!found) { s_modp[nmod] = randi; s_modv[nmod] = backv; nmod++; }
+          size--;
+          s_draw[k] = val;
+        }
+      }
+      __syncthreads();
+      double* pws = scratch;
+      double* us = scratch + 3 * (size_t)cap;
+      if (lane < mset) {
+        const float* q = g_p + (size_t)s_draw[lane] * 6;
+        pws[3 * lane] = q[2];
+        pws[3 * lane + 1] = q[3];
+        pws[3 * lane + 2] = q[4];
+        us[2 * lane] = q[0];
+        us[2 * lane + 1] = q[1];
+      }
+      __syncthreads();
+      epnp_refit_wave(mset, pws, us, scratch + 5 * (size_t)cap, scratch + 9 * (size_t)cap, cam, LDS_PTR(s_Rt[0]), r_ut, r_L, LDS_PTR(s_terms),
+                      LDS_PTR(s_red), LDS_PTR(s_mtm));
     }
     __syncthreads();
     PROF(12);
@@ -1193,10 +1257,16 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
     for (int h = 0; h < nact; h++) {
       const int cnt = s_cnt[h];
       if (cnt < minInl) continue;
-      if (cnt > best) {
+      const bool new_best = cnt > best;
+      if (new_best) {
         best = cnt;
         for (int w = lane; w < nwords; w += 64) s_best[w] = s_mask[h][w];
         for (int i = 0; i < 12; i++) bestT[i] = (float)s_Rt[h][i];
+      }
+      // Refine() runs on every hypothesis that reaches minInliers (src/PnPsolver.cc:216) but is a pure function of the best
+      // set: without a new best it repeats its last outcome -- a failure again (skipped), or, on a solver that has already
+      // returned a refined pose (a later iterate() call), the same success again
+      if (new_best || refine_ok) {
         __syncthreads();
         // Refine(): EPnP on the best inlier set (wave-cooperative), then CheckInliers
         double* pws = scratch;
@@ -1232,21 +1302,28 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
           rcnt += __popcll(bal);
         }
         __syncthreads();
-        if (rcnt > minInl) {   // accepted: mRefinedTcw / mvbRefinedInliers are returned (written in the common tail)
+        refine_ok = rcnt > minInl;
+        if (refine_ok) {   // accepted: mRefinedTcw / mvbRefinedInliers are returned (written in the common tail)
           accepted = 1;
           acc_iters = c0 + h + 1;
           acc_cnt = rcnt;
         }
       }
-      // cnt >= minInl but no new best: Refine() would refit the same best set and fail again
       if (accepted) break;
     }
     __syncthreads();
     PROF(14);
     if (accepted) break;
   }
-  // ---- common tail (uniform control flow): write the returned pose and inlier flags
+  // ---- common tail (uniform control flow): solver state, then the returned pose and inlier flags
   __syncthreads();
+  for (int w = lane; w < nwords; w += 64) st_mask[w] = s_best[w];
+  if (lane == 0) {
+    st[0] = accepted ? acc_iters : total;
+    st[1] = best;
+    st[2] = refine_ok;
+    for (int i = 0; i < 12; i++) st_T[i] = bestT[i];
+  }
   if (accepted) {
     for (int i = lane; i < N; i += 64)
       if ((s_ref[i >> 6] >> (i & 63)) & 1ull) inl_out[g_idx[i]] = 1;
@@ -1261,7 +1338,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
     }
     continue;
   }
-  // ---- iterations exhausted
+  // ---- iterations exhausted (mnIterations >= mRansacMaxIts holds whenever the loop ends without a return)
   if (lane == 0) {
     info[2] = 1;
     info[3] = total;

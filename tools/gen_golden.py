@@ -78,3 +78,22 @@ for seed in (20,):
                         tl_info=np.array([tl["status"], tl["n_points"], tl["n_inliers"], tl["n_local"]]), tl_T=tl["T"],
                         tl_local_match=tl["local_match"], tl_outlier=tl["outlier"])
 print("golden written to", OUT, sorted(os.listdir(OUT)))
+
+# PnP RANSAC on planted-outlier match vectors (tests/pnp_cases.py): every iterate() call of every scenario
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pnp_cases as PC                  # noqa: E402
+s = synth.make_scene(20)
+oc = O.OrbOracle(*cfg)
+ck, cd = oc.extract(s["cur"])
+tab = oc.tables()
+gold = {}
+for name, (kw, params, calls) in PC.SCENARIOS.items():
+    last, cm, truth = PC.planted(7, ck, s["T_cur"], **kw)
+    rs = synth.glibc_rand_stream(PC.rand_needed(params, calls))
+    res, pr = PC.run_oracle(O, ck, tab["sigma2"], last, cm, params, calls, rs)
+    gold[name + "_params"] = np.array([pr["N"], pr["min_inliers"], pr["max_its"]])
+    gold[name + "_info"] = np.array([[r["ok"], r["iterations"], r["n_inliers"], r["no_more"]] for r in res], np.int32)
+    gold[name + "_inliers"] = np.stack([r["inliers"] for r in res])
+    gold[name + "_T"] = np.stack([r["T"] for r in res])
+np.savez_compressed(os.path.join(OUT, "pnp_ransac_seed20.npz"), **gold)
+print("pnp golden:", {k: v.tolist() for k, v in gold.items() if k.endswith("_info")})
