@@ -235,6 +235,16 @@ int sd_track_get_tracked(sd_track* h, int frame0, int n_frames, int32_t* info4);
 int sd_track_local_map(sd_track* h, int n_frames, float th, float nnratio, float viewing_cos_limit, int min_inliers);
 int sd_track_get_local_map(sd_track* h, int frame0, int n_frames, int32_t* map_match, int cap, int32_t* info4);
 
+/* ORBmatcher::SearchByPoints(KeyFrame* currentKF, KeyFrame* pKF, vector<MapPoint*>& matches)
+ *   src/ORBmatcher.h:56, src/ORBmatcher.cc:1209-1301 (caller: LoopClosing::ComputeSim3, src/LoopClosing.cc:255)
+ * Brute-force Hamming matching between the map points of two keyframes, for the whole batch: slot f pairs frame f (or the
+ * broadcast frame) of the cur extractor with frame f of the ref extractor.  has_mp_cur / has_mp_ref [n_frames][cap]:
+ * GetMapPointMatches()[i] != NULL && !isBad().  nnratio = mfNNratio (0.75 in ComputeSim3), check_ori = mbCheckOrientation.
+ * matches12[i] = index of the pKF keypoint whose map point the reference stores in matches[i], or -1; *n_matches = return value. */
+int sd_track_set_point_flags(sd_track* h, int frame0, int n_frames, const uint8_t* has_mp_cur, const uint8_t* has_mp_ref, int cap);
+int sd_track_search_by_points(sd_track* h, int n_frames, float nnratio, int check_ori);
+int sd_track_get_point_matches(sd_track* h, int frame0, int n_frames, int32_t* matches12, int cap, int32_t* n_matches);
+
 int sd_track_align(sd_track* h, int n_frames, int mode);
 int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori);
 /* sd_track_pnp = PnPsolver(CurrentFrame, CurrentFrame.mvpMapPoints) + SetRansacParameters(...) + iterate(n_iterations)
@@ -272,6 +282,11 @@ int sd_debug_sel_prof(unsigned long long* out64, int reset);   /* k_select_level
 int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy,
                   double* R9, double* t3, double* reproj_err);
 int sd_track_debug_read(sd_track* h, int which, int frame, void* out, size_t bytes);
+/* Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (src/Frame.cc:271-321) answered by the device-side bucket grid of
+ * current frame `frame` (Frame::AssignFeaturesToGrid, src/Frame.cc:179-192 -- the grid the matchers build): keypoint
+ * indices in the reference's vIndices order; grid_counts (may be NULL) = mGrid[x][y].size(), [64][48]. */
+int sd_track_debug_features_in_area(sd_track* h, int frame, float x, float y, float r, int min_level, int max_level,
+                                    int32_t* indices, int cap, int32_t* n_out, int32_t* grid_counts);
 int sd_track_set_profiling(sd_track* h, int on);
 int sd_track_stage_ms(sd_track* h, float* ms_out /* [0]=align, [1]=match, [2]=pnp */, int cap);
 

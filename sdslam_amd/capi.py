@@ -558,6 +558,35 @@ class Tracker:
                     no_more=info[:, 2].astype(bool), iterations=info[:, 3], N=info[:, 4], min_inliers=info[:, 5],
                     max_its=info[:, 6], refined=info[:, 7].astype(bool))
 
+    def set_point_flags(self, frame0, has_mp_cur, has_mp_ref):
+        a, b = np.ascontiguousarray(has_mp_cur, np.uint8), np.ascontiguousarray(has_mp_ref, np.uint8)
+        assert a.ndim == 2 and a.shape == b.shape
+        self.L.sd_track_set_point_flags.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        _check(self.L.sd_track_set_point_flags(self.h, frame0, a.shape[0], _p(a), _p(b), a.shape[1]))
+
+    def search_by_points(self, n_frames, nnratio=0.75, check_ori=True):
+        """ORBmatcher::SearchByPoints(currentKF, pKF, matches): brute-force Hamming between two keyframes' map points."""
+        self.L.sd_track_search_by_points.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int]
+        _check(self.L.sd_track_search_by_points(self.h, n_frames, float(nnratio), int(check_ori)))
+
+    def get_point_matches(self, frame0, n):
+        m = np.zeros((n, self.cap), np.int32)
+        nm = np.zeros(n, np.int32)
+        self.L.sd_track_get_point_matches.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        _check(self.L.sd_track_get_point_matches(self.h, frame0, n, _p(m), self.cap, _p(nm)))
+        return m, nm
+
+    def features_in_area(self, frame, x, y, r, min_level=-1, max_level=-1, want_grid=False):
+        """Frame::GetFeaturesInArea on the device grid of current frame `frame` (debug read-out)."""
+        idx = np.zeros(self.cap, np.int32)
+        n = C.c_int32(0)
+        grid = np.zeros((64, 48), np.int32) if want_grid else None
+        self.L.sd_track_debug_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                                           C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _check(self.L.sd_track_debug_features_in_area(self.h, frame, x, y, r, min_level, max_level, _p(idx), self.cap, C.byref(n),
+                                                      _p(grid) if want_grid else None))
+        return (idx[:n.value].copy(), grid) if want_grid else idx[:n.value].copy()
+
     def set_profiling(self, on=True):
         _check(self.L.sd_track_set_profiling(self.h, int(on)))
 

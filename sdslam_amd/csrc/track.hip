@@ -123,6 +123,10 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.pnp_state, B * 4));
   A(dalloc(h, &tb.pnp_best_mask, B * 32));
   A(dalloc(h, &tb.pnp_best_T, B * 12));
+  A(dalloc(h, &tb.sp_valid1, B * K));
+  A(dalloc(h, &tb.sp_valid2, B * K));
+  A(dalloc(h, &tb.sp_match, B * K));
+  A(dalloc(h, &tb.sp_n, B));
   A(dalloc(h, &tb.lm_cand, B * M));
   A(dalloc(h, &tb.lm_Xw, B * M * 3));
   A(dalloc(h, &tb.lm_normal, B * M * 3));
@@ -680,6 +684,53 @@ int sd_track_get_stereo(sd_track* h, int frame0, int n_frames, float* uright, fl
   return SD_OK;
 }
 
+// ORBmatcher::SearchByPoints(currentKF, pKF, matches) (reference src/ORBmatcher.cc:1209-1301) for the batch: slot f matches
+// the keypoints of current frame f (or the broadcast frame) that hold a map point against those of frame f of the ref
+// extractor.  has_mp_* = "GetMapPointMatches()[i] != NULL && !isBad()", [n_frames][cap], rows shorter than the keypoint
+// capacity are padded with 0.
+int sd_track_set_point_flags(sd_track* h, int frame0, int n_frames, const uint8_t* has_mp_cur, const uint8_t* has_mp_ref, int cap) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(has_mp_cur && has_mp_ref && cap >= 1 && cap <= h->kp_cap, SD_ERR_INVALID_ARG, "bad flag arrays (cap must be 1..keypoint capacity)");
+  hipStream_t s = h->cur->stream;
+  const size_t K = h->kp_cap, o = (size_t)frame0 * K;
+  SD_HIP_CHECK(hipMemsetAsync(h->tb.sp_valid1 + o, 0, (size_t)n_frames * K, s));
+  SD_HIP_CHECK(hipMemsetAsync(h->tb.sp_valid2 + o, 0, (size_t)n_frames * K, s));
+  SD_HIP_CHECK(hipMemcpy2DAsync(h->tb.sp_valid1 + o, K, has_mp_cur, (size_t)cap, (size_t)cap, n_frames, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpy2DAsync(h->tb.sp_valid2 + o, K, has_mp_ref, (size_t)cap, (size_t)cap, n_frames, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
+}
+
+int sd_track_search_by_points(sd_track* h, int n_frames, float nnratio, int check_ori) {
+  int rc = check_ready(h, n_frames);
+  if (rc != SD_OK) return rc;
+  SD_REQUIRE(h->ref->have_geom && h->ref->last_frames >= n_frames, SD_ERR_INVALID_ARG, "keyframes of the ref extractor have not been extracted");
+  int nsel_ref = 0;
+  for (int q : h->ref->hp.quota) nsel_ref += q;
+  SD_REQUIRE(nsel_ref == h->kp_cap, SD_ERR_INVALID_ARG, "cur / ref extractors must share the keypoint capacity");
+  hipStream_t s = h->pnp_stream;
+  rc = wait_inputs(h, true);
+  if (rc != SD_OK) return rc;
+  hipEvent_t* ev = h->ev[h->ev_calls[1] % sd_track::kRing];   // timed in the matcher's slot
+  if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev[2], s));
+  rc = launch_search_points(h->cur, h->ref, h->tb, n_frames, nnratio, check_ori, s);
+  if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev[3], s)); h->ev_calls[1]++; }
+  if (rc == SD_OK) rc = mark_reads(h, true);
+  return rc;
+}
+
+int sd_track_get_point_matches(sd_track* h, int frame0, int n_frames, int32_t* matches12, int cap, int32_t* n_matches) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(!matches12 || cap >= h->kp_cap, SD_ERR_CAPACITY, "cap smaller than the keypoint capacity");
+  hipStream_t s = h->cur->stream;
+  if (matches12)
+    SD_HIP_CHECK(hipMemcpy2DAsync(matches12, (size_t)cap * 4, h->tb.sp_match + (size_t)frame0 * h->kp_cap, (size_t)h->kp_cap * 4,
+                                  (size_t)h->kp_cap * 4, n_frames, hipMemcpyDeviceToHost, s));
+  if (n_matches) SD_HIP_CHECK(hipMemcpyAsync(n_matches, h->tb.sp_n + frame0, (size_t)n_frames * 4, hipMemcpyDeviceToHost, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
+}
+
 // PnPsolver(F, vpMapPointMatches) accepts ANY match vector (reference src/PnPsolver.cc:71-110), and so does
 // Optimizer::PoseOptimization through pFrame->mvpMapPoints: this replaces the slot's CurrentFrame.mvpMapPoints (indices into
 // the last-frame arrays, -1 = NULL) with the caller's, as if a search had produced them.
@@ -843,6 +894,34 @@ int sd_track_debug_read(sd_track* h, int which, int frame, void* out, size_t byt
   const void* src = which == 0 ? (const void*)(h->tb.pnp_pts + (size_t)frame * h->kp_cap * 6)
                                : (const void*)(h->tb.pnp_kpidx + (size_t)frame * h->kp_cap);
   SD_HIP_CHECK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+  return SD_OK;
+}
+
+// Frame::GetFeaturesInArea (src/Frame.cc:271-321) on the device grid of current frame `frame` (the grid k_match builds):
+// indices in the reference's order; grid_counts (may be NULL): mGrid[x][y].size() as [64][48] ints.
+int sd_track_debug_features_in_area(sd_track* h, int frame, float x, float y, float r, int min_level, int max_level, int32_t* indices,
+                                    int cap, int32_t* n_out, int32_t* grid_counts) {
+  int rc = check_ready(h, frame + 1, true);
+  if (rc != SD_OK) return rc;
+  SD_REQUIRE(frame >= 0 && indices && n_out && cap >= 0, SD_ERR_INVALID_ARG, "bad arguments");
+  hipStream_t s = h->pnp_stream;
+  rc = wait_inputs(h, false);
+  if (rc != SD_OK) return rc;
+  int32_t* d = nullptr;
+  const size_t n_ints = (size_t)h->kp_cap + 1 + 64 * 48;
+  SD_HIP_CHECK(hipMalloc(&d, n_ints * 4));
+  rc = launch_features_in_area(h->cur, h->tb, h->cam, frame, x, y, r, min_level, max_level, d, h->kp_cap, d + h->kp_cap, d + h->kp_cap + 1, s);
+  std::vector<int32_t> host(n_ints);
+  hipError_t e = hipMemcpyAsync(host.data(), d, n_ints * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d);
+  if (rc != SD_OK) return rc;
+  if (e != hipSuccess) { set_error(std::string("sd_track_debug_features_in_area: ") + hipGetErrorString(e)); return SD_ERR_HIP; }
+  const int n = host[h->kp_cap];
+  *n_out = n;
+  SD_REQUIRE(n <= cap, SD_ERR_CAPACITY, "indices array too small");
+  std::memcpy(indices, host.data(), (size_t)n * 4);
+  if (grid_counts) std::memcpy(grid_counts, host.data() + h->kp_cap + 1, 64 * 48 * 4);
   return SD_OK;
 }
 

@@ -47,6 +47,11 @@ struct TrackBuffers {
   int32_t* pnp_state;    // [B][4]: mnIterations, mnBestInliers, Refine() outcome for the current best set, 0
   unsigned long long* pnp_best_mask;   // [B][32] mvbBestInliers as bits over the gathered correspondences
   float* pnp_best_T;     // [B][12] mBestTcw (R row-major, t)
+  // ORBmatcher::SearchByPoints (brute-force Hamming between two keyframes' map points)
+  uint8_t* sp_valid1;    // [B][kp_cap] currentKF keypoint holds a map point that is not bad
+  uint8_t* sp_valid2;    // [B][kp_cap] the same for pKF (the `ref` extractor's frame)
+  int32_t* sp_match;     // [B][kp_cap] pKF keypoint index assigned to the currentKF keypoint, or -1
+  int32_t* sp_n;         // [B]
   // local map (TrackLocalMap's search); capacity M like the last-frame arrays
   uint8_t* lm_cand;      // [B][M]   point reaches isInFrustum (not bad, not already seen in this frame)
   double* lm_Xw;         // [B][M][3]
@@ -106,6 +111,10 @@ int launch_pose_opt(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& c
 // (tb.cur_match / tb.obs) instead of the caller's lm_kclaim flags
 int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, const float* d_scale_thr,
                        int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s, int claim_from_matches = 0);
+int launch_features_in_area(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, int frame, float x, float y, float r,
+                            int min_level, int max_level, int32_t* d_out, int out_cap, int32_t* d_n, int32_t* d_grid, hipStream_t s);
+int launch_search_points(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, int n_frames, float nnratio, int check_ori,
+                         hipStream_t s);
 int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_depth, int w, int h,
                              int stride_elems, size_t frame_stride_elems, int n_frames, hipStream_t s);
 int read_pnp_prof(unsigned long long* out32, int reset);

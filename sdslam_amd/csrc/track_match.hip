@@ -152,6 +152,46 @@ __device__ __forceinline__ uint32_t match_window(float u, float v, float radius,
   return MODE == 2 ? best : (uint32_t)w;
 }
 
+// ---- Frame bucket grid (shared by k_match, k_match_local and the debug read-out k_features_in_area) ----
+// Frame::PosInGrid (src/Frame.cc:323-332, round()) as a sort key: cell << 11 | keypoint index, cell = posX * 48 + posY;
+// 0xFFFFFFFF for a keypoint outside the grid (AssignFeaturesToGrid skips it).
+__device__ __forceinline__ uint32_t grid_key(const sd_keypoint& kp, const TrackCam& cam, float invW, float invH, int i) {
+  const int posX = (int)roundf((kp.x - cam.min_x) * invW);
+  const int posY = (int)roundf((kp.y - cam.min_y) * invH);
+  if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) return 0xFFFFFFFFu;
+  return ((uint32_t)(posX * GRID_ROWS + posY) << 11) | (uint32_t)i;
+}
+// Frame::AssignFeaturesToGrid (src/Frame.cc:179-192): bitonic sort of the KP2 keys in LDS (mGrid[x][y] in ascending
+// keypoint index = one contiguous, ordered run per cell) and the first sorted position of every cell.  All NT threads
+// call, after a barrier that makes s_key complete; ends with s_cstart written but NOT yet synchronised.
+__device__ __forceinline__ void grid_sort_and_starts(uint32_t* s_key, uint16_t* s_cstart, int KP2, int tid, int NT) {
+  for (int k = 2; k <= KP2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < KP2; i += NT) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          uint32_t a = s_key[i], b = s_key[ixj];
+          bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            s_key[i] = b;
+            s_key[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (int c = tid; c <= GRID_COLS * GRID_ROWS; c += NT) {
+    const uint32_t target = (uint32_t)c << 11;
+    int lo = 0, hi = KP2;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (s_key[mid] < target) lo = mid + 1;
+      else hi = mid;
+    }
+    s_cstart[c] = (uint16_t)lo;
+  }
+}
+
 // a16 / a17: projection of last-frame point i (src/ORBmatcher.cc:974-1004) and its window
 template <int MODE, int GL = 64>
 __device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
@@ -234,9 +274,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
     if (i < N) {
       const sd_keypoint kp = kps[i];
       ang = kp.angle;
-      const int posX = (int)roundf((kp.x - cam.min_x) * G.invW);
-      const int posY = (int)roundf((kp.y - cam.min_y) * G.invH);
-      if (!(posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS)) key = ((uint32_t)(posX * GRID_ROWS + posY) << 11) | (uint32_t)i;
+      key = grid_key(kp, cam, G.invW, G.invH, i);
     }
     s_key[i] = key;
     s_kang[i] = ang;
@@ -259,31 +297,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const sd_keypoint* __re
   if (tid < HISTO_LENGTH) s_hist[tid] = 0;
   if (tid == 0) *s_nlist = 0;
   __syncthreads();
-  for (int k = 2; k <= KP2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < KP2; i += NT) {
-        int ixj = i ^ j;
-        if (ixj > i) {
-          uint32_t a = s_key[i], b = s_key[ixj];
-          bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            s_key[i] = b;
-            s_key[ixj] = a;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  for (int c = tid; c <= GRID_COLS * GRID_ROWS; c += NT) {
-    const uint32_t target = (uint32_t)c << 11;
-    int lo = 0, hi = KP2;
-    while (lo < hi) {
-      int mid = (lo + hi) >> 1;
-      if (s_key[mid] < target) lo = mid + 1;
-      else hi = mid;
-    }
-    s_cstart[c] = (uint16_t)lo;
-  }
+  grid_sort_and_starts(s_key, s_cstart, KP2, tid, NT);
   {
     // column-major; the retry searches from the predicted pose, which becomes the frame's pose (SetPose(predicted_pose))
     const double* Tc = (retry_below > 0 ? tb.Tprior : tb.Tcur) + (size_t)f * 16;
@@ -487,9 +501,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
     if (i < N) {
       const sd_keypoint kp = kps[i];
       oct = kp.octave;
-      const int posX = (int)roundf((kp.x - cam.min_x) * invW);
-      const int posY = (int)roundf((kp.y - cam.min_y) * invH);
-      if (!(posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS)) key = ((uint32_t)(posX * GRID_ROWS + posY) << 11) | (uint32_t)i;
+      key = grid_key(kp, cam, invW, invH, i);
     }
     s_key[i] = key;
     s_koct[i] = (uint8_t)oct;
@@ -524,31 +536,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
   }
   if (tid == 0) *s_nlist = 0;
   __syncthreads();
-  for (int k = 2; k <= KP2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < KP2; i += NT) {
-        int ixj = i ^ j;
-        if (ixj > i) {
-          uint32_t a = s_key[i], b = s_key[ixj];
-          bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            s_key[i] = b;
-            s_key[ixj] = a;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  for (int c = tid; c <= GRID_COLS * GRID_ROWS; c += NT) {
-    const uint32_t target = (uint32_t)c << 11;
-    int lo = 0, hi = KP2;
-    while (lo < hi) {
-      int mid = (lo + hi) >> 1;
-      if (s_key[mid] < target) lo = mid + 1;
-      else hi = mid;
-    }
-    s_cstart[c] = (uint16_t)lo;
-  }
+  grid_sort_and_starts(s_key, s_cstart, KP2, tid, NT);
   // ---- isInFrustum, one thread per point
   {
     const double* Tc = tb.Tcur + (size_t)f * 16;   // column-major
@@ -727,6 +715,58 @@ int launch_stereo_from_depth(const sd_orb* cur, const TrackBuffers& tb, const Tr
                              int stride_elems, size_t frame_stride_elems, int n_frames, hipStream_t s) {
   hipLaunchKernelGGL(k_stereo_from_depth, dim3((tb.kp_cap + 255) / 256, n_frames), dim3(256), 0, s, cur->d_kps,
                      (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam, d_depth, w, h, stride_elems, frame_stride_elems);
+  SD_HIP_CHECK(hipGetLastError());
+  return SD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Debug read-out of the device grid: Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (src/Frame.cc:271-321) for
+// one current frame, through the SAME grid build and window walk the matchers use (grid_key / grid_sort_and_starts /
+// match_window).  out[0 .. n) = keypoint indices in the reference's vIndices order; grid_cells (may be null) receives
+// mGrid's occupancy, [64][48] counts.  Lets the parity tests compare a13 / a14 directly instead of through match vectors.
+__global__ __launch_bounds__(64 * MT_WAVES) void k_features_in_area(const sd_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                                     const int32_t* __restrict__ nkp, const float* __restrict__ uright,
+                                                                     TrackCam cam, int cap, int KP2, float x, float y, float r, int minLevel,
+                                                                     int maxLevel, int32_t* __restrict__ out, int out_cap,
+                                                                     int32_t* __restrict__ n_out, int32_t* __restrict__ grid_cells) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* s_key = (uint32_t*)smem;
+  uint32_t* s_list = s_key + KP2;
+  uint16_t* s_cstart = (uint16_t*)(s_list + KP2);
+  const int tid = threadIdx.x, lane = tid & 63, NT = 64 * MT_WAVES;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int N = min(nkp[0], min(cap, KP2));
+  const float invW = (float)GRID_COLS / (float)(cam.max_x - cam.min_x);
+  const float invH = (float)GRID_ROWS / (float)(cam.max_y - cam.min_y);
+  __shared__ __attribute__((aligned(16))) uint8_t zero_desc[32];
+  if (tid < 32) zero_desc[tid] = 0;
+  for (int i = tid; i < KP2; i += NT) s_key[i] = i < N ? grid_key(kps[i], cam, invW, invH, i) : 0xFFFFFFFFu;
+  __syncthreads();
+  grid_sort_and_starts(s_key, s_cstart, KP2, tid, NT);
+  __syncthreads();
+  if (grid_cells)
+    for (int c = tid; c < GRID_COLS * GRID_ROWS; c += NT) grid_cells[c] = (int)s_cstart[c + 1] - (int)s_cstart[c];
+  if (tid >= 64) return;
+  const MatchLds SL = {s_key, s_cstart, nullptr, nullptr, nullptr};
+  int seq = 0;
+  // the matchers' stereo gate (|ur - mvuRight[idx]| > radius rejects) is not part of GetFeaturesInArea: ur = NaN makes the
+  // comparison false for every keypoint, whatever mvuRight holds
+  const int cnt = (int)match_window<1>(x, y, r, minLevel, maxLevel, __builtin_nanf(""), zero_desc, kps, desc, uright, SL, cam, invW, invH, s_list, lane, lt, &seq);
+  // keys are (dist << 22 | order << 11 | idx); emitted in walk order already (list position = order among the survivors)
+  for (int j = lane; j < min(cnt, out_cap); j += 64) out[j] = (int32_t)(s_list[j] & 2047);
+  if (lane == 0) *n_out = cnt;
+}
+
+int launch_features_in_area(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, int frame, float x, float y, float r,
+                            int min_level, int max_level, int32_t* d_out, int out_cap, int32_t* d_n, int32_t* d_grid, hipStream_t s) {
+  int KP2 = 64;
+  while (KP2 < tb.kp_cap) KP2 <<= 1;
+  SD_REQUIRE(KP2 <= MT_MAXKP, SD_ERR_CAPACITY, "matcher supports at most 2048 keypoints per frame");
+  const size_t lds = (size_t)KP2 * 8 + (GRID_COLS * GRID_ROWS + 2) * 2;
+  const sd_keypoint* kps = (cur->have_dist ? cur->d_kps_un : cur->d_kps) + (size_t)frame * tb.kp_cap;
+  hipLaunchKernelGGL(k_features_in_area, dim3(1), dim3(64 * MT_WAVES), lds, s, kps, cur->d_desc + (size_t)frame * tb.kp_cap * 32,
+                     cur->d_nout + frame, tb.uright + (size_t)frame * tb.kp_cap, cam, tb.kp_cap, KP2, x, y, r, min_level, max_level, d_out,
+                     out_cap, d_n, d_grid);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }
