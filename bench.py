@@ -7,27 +7,38 @@ Workload (BASELINE.json metric: "tracked frames/sec (ORB+ImageAlign+PnP) at 640x
 one *step* tracks a batch of B independent 640x480 frames, all resident in HBM:
     ORB extract (8 levels x1.2, 1000 kp)  ->  ImageAlign (levels 4,3,2, <=30 GN its each)
     ->  SearchByProjection (th 8, mono, orientation check)  ->  PnP RANSAC (<=200 its, EPnP)
-i.e. the TrackWithMotionModel sequence of SURVEY.md §3.2 / config C4.  The last frames'
-pyramids, map points and the predicted poses are set up (untimed) beforehand, exactly as they
-would be left behind by the previous tracking step.  With N > 1 the driver launches one rank
-per GPU (torch.distributed / RCCL); frames are independent, so ranks share nothing on the data
-path (weak scaling); the fixed-size per-frame pose records are all-gathered once.
-Rank 0 prints ONE JSON line.
+    ->  the batch's 160-byte pose records packed on the device
+i.e. the TrackWithMotionModel sequence of SURVEY.md §3.2 / config C4.  The last frames' pyramids, map points and the
+predicted poses are set up (untimed) beforehand, exactly as the previous tracking step would have left them.
 
-Variants of the step (same metric name, `config.pose_solver` says which): --pose-solver poseopt replaces PnP RANSAC by
-Optimizer::PoseOptimization (what the reference's TrackWithMotionModel really calls, SURVEY D1); motion_model runs the
-whole Tracking::TrackWithMotionModel as one device-side call; track adds Tracking::TrackLocalMap over a ~1000-point
-local map.  --orb-only times the extraction alone, --res WxH other frame sizes, --batch 1 the single-frame latency.
+N > 1: one process per GPU over torch.distributed (backend nccl = RCCL).  Either the driver launches the ranks
+(torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE in the environment) or `python bench.py --gpus N` starts N child
+ranks itself.  Frames are independent, so ranks share nothing on the data path (weak scaling: B frames per GPU); the only
+exchange is ONE all-gather per step of the fixed-size pose records, issued INSIDE the timed region straight from the
+device buffer the last tracking kernel wrote.  Rank 0 prints ONE JSON line.
+
+Variants (same metric name, `config.pose_solver` says which): --pose-solver poseopt = Optimizer::PoseOptimization instead
+of PnP RANSAC (what the reference's TrackWithMotionModel really calls); motion_model = the whole
+Tracking::TrackWithMotionModel as one device-side call; track adds Tracking::TrackLocalMap over a ~1000-point local map.
+--orb-only times extraction alone, --hamming extraction + brute-force SearchByPoints (BASELINE configs[1]: "ORB extract +
+Hamming match"), --res WxH other frame sizes, --batch 1 the single-frame latency.
 
 Extra objects in the line:
-  roofline     -- the dominant kernel stage: algorithmic bytes per launch / its mean
-                  duration, measured with HIP events on the launch stream inside the timed region
-  cpu_baseline -- the CPU oracle (a port of the reference path; the reference itself needs
-                  OpenCV/Eigen and cannot be built here) timed on this host, 1 core, bounded sample
+  roofline     -- dominant kernel stage: algorithmic bytes per launch / its mean duration (HIP events on the
+                  launch stream inside the timed region) against HBM peak; `valu` = the same stage against the measured
+                  vector-ALU issue rate, `traffic` = HBM bytes from the committed rocprofv3 PMC passes
+  cpu_baseline -- the CPU oracle (a port of the reference path; the reference needs OpenCV/Eigen and cannot be built
+                  here) timed on this host: 1 thread (the reference's tracking is single-threaded) with median / p95 per
+                  stage, and all cores (one independent frame stream per core)
+  stress       -- the hard cases the default workload does not reach: ImageAlign from an identity prior, PnP RANSAC on 40 %
+                  outliers, PnP RANSAC forced through all 200 iterations
+  h2d_inclusive -- frames/s when every step first uploads its frames from page-locked host memory (never `value`)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,27 +47,38 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CFG = (1000, 1.2, 8, 20)
 W, H = 640, 480
 BOUNDS = (0.0, 640.0, 0.0, 480.0)
 PNP = dict(probability=0.99, min_inliers=10, max_iterations=200, min_set=4, epsilon=0.28, th2=5.991)
+RECORD_SOURCE = {"pnp": 0, "poseopt": 1, "motion_model": 2, "track": 3}
+# Vector-ALU issue model (measured by tools/valu_microbench.py on this GPU): one wave64 VALU instruction
+# occupies a SIMD for VALU_CYCLES cycles once >= 2 waves are resident; 256 CUs x 4 SIMDs at CLK_GHZ.
+N_SIMD, CLK_GHZ, VALU_CYCLES = 1024, 2.4, 2.0
 
 
-def make_cases(n_unique, seed0, w=640, h=480):
-    """n_unique two-view scenes (SURVEY §8d C3/C4) with slightly different motions."""
+def _scene(args):
+    i, seed0, w, h = args
     from sdslam_amd import synth
-    rng = np.random.default_rng(seed0)
-    scenes = []
-    for i in range(n_unique):
-        ups = np.array([0.02, -0.01, 0.015]) + rng.normal(size=3) * 0.004
-        om = np.array([0.4, -0.3, 0.5]) + rng.normal(size=3) * 0.1
-        scenes.append(synth.make_scene(seed0 + i, tuple(ups), tuple(om), w, h))
-    return scenes
+    rng = np.random.default_rng(seed0 + 7919 * i)
+    ups = np.array([0.02, -0.01, 0.015]) + rng.normal(size=3) * 0.004
+    om = np.array([0.4, -0.3, 0.5]) + rng.normal(size=3) * 0.1
+    return synth.make_scene(seed0 + i, tuple(ups), tuple(om), w, h)
 
 
-def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0, pose_solver="pnp", locals_=None):
-    """The oracle's full tracking step (-O3 -march=native build) on this host: 1 thread."""
+def make_cases(n_unique, seed0, w=640, h=480, pool=None):
+    """n_unique two-view scenes (SURVEY §8d C3/C4) with slightly different motions."""
+    jobs = [(i, seed0, w, h) for i in range(n_unique)]
+    return pool.map(_scene, jobs) if pool is not None else [_scene(j) for j in jobs]
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+STAGES_CPU = ["pyramid", "fast_nms", "select", "ic_angle", "blur", "rbrief", "image_align", "search_by_projection", "pose_solve"]
+
+
+def cpu_loop(scenes, lasts, T0s, rs, budget_s, pose_solver="pnp", locals_=None, max_frames=1000, warm=2):
+    """The oracle's full tracking step (-O3 -march=native build), one thread: per-frame stage times [n, 9] in ms."""
     from oracle import oracle as O
     from sdslam_amd import synth
     K = (synth.FX, synth.FY, synth.CX, synth.CY)
@@ -67,68 +89,108 @@ def cpu_baseline(scenes, lasts, T0s, rs, budget_s=15.0, pose_solver="pnp", local
     ref_pyr = [[o.level(l) for l in range(CFG[2])] for o in ora_ref]
     cur = O.OrbOracle(*CFG, fast_build=True)
     tab = cur.tables()
+    rows = []
     t0 = time.perf_counter()
     n = 0
-    t_stage = np.zeros(4)
     while True:
         i = n % len(scenes)
         s, last = scenes[i], lasts[i]
-        ta = time.perf_counter()
         ck, cd = cur.extract(s["cur"])
-        tb = time.perf_counter()
-        pc = [cur.level(l) for l in range(CFG[2])]
-        tb2 = time.perf_counter()
-        if pose_solver in ("motion_model", "track"):      # the reference functions as a whole (oracle composition of the same stages)
+        st = list(cur.stage_ns() / 1e6)
+        pc = [cur.level(l) for l in range(CFG[2])]          # Python-side copies between the C calls: not timed
+        ta = time.perf_counter()
+        if pose_solver in ("motion_model", "track"):          # the reference functions as a whole (oracle composition)
             r = O.track_with_motion_model(pc, ref_pyr[i], tab, ck, cd, BOUNDS, K, s["T_ref"], T0s[i], last, 8.0, mono=True)
-            tl = time.perf_counter()
+            tb = time.perf_counter()
             if pose_solver == "track":
                 O.track_local_map(ck, cd, tab, np.log(np.float32(CFG[1])), BOUNDS, K, r["T"], r["match"], last, locals_[i], th=1.0)
-            te = time.perf_counter()
-            t_stage += [tb - ta, tl - tb2, te - tl, 0.0]
-            n += 1
-            if time.perf_counter() - t0 > budget_s or n >= 1000:
-                break
-            continue
-        r = O.align(pc, ref_pyr[i], tab["inv_sf"], tab["sf"], last["Xw"][last["valid"] != 0], s["T_ref"], T0s[i], K, 0)
-        tc = time.perf_counter()
-        nm, cm = O.search_by_projection(ck, cd, tab["sf"], BOUNDS, K, r["T"], s["T_ref"], last, th=8.0)
-        td = time.perf_counter()
-        valid = (cm >= 0).astype(np.uint8)
-        Xw = np.zeros((len(ck), 3))
-        Xw[valid != 0] = last["Xw"][cm[valid != 0]]
-        if pose_solver == "pnp":
-            p = O.PnPOracle(valid, np.stack([ck["x"], ck["y"]], 1), ck["octave"], tab["sigma2"], Xw, K)
-            p.set_ransac(PNP["probability"], PNP["min_inliers"], PNP["max_iterations"], 4, PNP["epsilon"], PNP["th2"])
-            p.iterate(PNP["max_iterations"], rs)
+            tc = time.perf_counter()
+            st += [(tb - ta) * 1e3, (tc - tb) * 1e3, 0.0]
         else:
-            O.pose_optimization(ck, valid, Xw, tab["inv_sigma2"], K, r["T"])
-        te = time.perf_counter()
-        t_stage += [tb - ta, tc - tb2, td - tc, te - td]
+            r = O.align(pc, ref_pyr[i], tab["inv_sf"], tab["sf"], last["Xw"][last["valid"] != 0], s["T_ref"], T0s[i], K, 0)
+            tb = time.perf_counter()
+            nm, cm = O.search_by_projection(ck, cd, tab["sf"], BOUNDS, K, r["T"], s["T_ref"], last, th=8.0)
+            tc = time.perf_counter()
+            valid = (cm >= 0).astype(np.uint8)
+            Xw = np.zeros((len(ck), 3))
+            Xw[valid != 0] = last["Xw"][cm[valid != 0]]
+            if pose_solver == "pnp":
+                p = O.PnPOracle(valid, np.stack([ck["x"], ck["y"]], 1), ck["octave"], tab["sigma2"], Xw, K)
+                p.set_ransac(PNP["probability"], PNP["min_inliers"], PNP["max_iterations"], 4, PNP["epsilon"], PNP["th2"])
+                p.iterate(PNP["max_iterations"], rs)
+            else:
+                O.pose_optimization(ck, valid, Xw, tab["inv_sigma2"], K, r["T"])
+            td = time.perf_counter()
+            st += [(tb - ta) * 1e3, (tc - tb) * 1e3, (td - tc) * 1e3]
         n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 1000:
+        if n > warm:
+            rows.append(st)
+        if time.perf_counter() - t0 > budget_s or len(rows) >= max_frames:
             break
-    dt = t_stage.sum()      # excludes the Python-side pyramid copies between the C calls
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} VGA frame pairs, full step (ORB extract + ImageAlign + SearchByProjection + "
-                      f"{'PnP RANSAC' if pose_solver == 'pnp' else 'PoseOptimization'}"
-                      f"{', composed as Tracking::TrackWithMotionModel (align+match+pose under image_align)' if pose_solver in ('motion_model', 'track') else ''}"
-                      f"{' + Tracking::TrackLocalMap (under search_by_projection)' if pose_solver == 'track' else ''}), "
-                      f"1 thread of {os.cpu_count()} host cpus",
-            "ms_per_frame": {"orb_extract": t_stage[0] / n * 1e3, "image_align": t_stage[1] / n * 1e3,
-                             "search_by_projection": t_stage[2] / n * 1e3, "pose_solve": t_stage[3] / n * 1e3}}
+    return np.array(rows)
 
 
-STAGE_KERNELS = {"pyramid": ["k_pyr_resize", "k_pyr_edges", "k_pyr_rows", "k_pyr_level"], "fast_nms": ["k_fast_cells"],
+def cpu_worker_main(argv):
+    """`bench.py --cpu-worker SEED BUDGET POSE_SOLVER`: one independent frame stream on one core (the all-cores leg)."""
+    seed, budget, solver = int(argv[0]), float(argv[1]), argv[2]
+    from oracle import oracle as O
+    from sdslam_amd import synth
+    scenes = make_cases(1, seed)
+    orf = O.OrbOracle(*CFG, fast_build=True)
+    rk, rd = orf.extract(scenes[0]["ref"])
+    lasts = [synth.tracking_case(0, rk, rd)]
+    T0 = [synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04)) @ scenes[0]["T_cur"]]
+    rs = synth.glibc_rand_stream(4 * PNP["max_iterations"])
+    loc = None
+    if solver == "track":
+        oc = O.OrbOracle(*CFG, fast_build=True)
+        ck, cd = oc.extract(scenes[0]["cur"])
+        loc = [{k: v[:1000] for k, v in synth.local_map_case(500, ck, cd, scenes[0]["T_cur"]).items()}]
+    t0 = time.perf_counter()
+    rows = cpu_loop(scenes, lasts, T0, rs, budget, solver if solver != "hamming" else "pnp", loc, max_frames=100000, warm=1)
+    print(json.dumps({"frames": len(rows), "busy_s": float(rows.sum() / 1e3), "wall_s": time.perf_counter() - t0}))
+
+
+def cpu_baseline(scenes, lasts, T0s, rs, pose_solver="pnp", locals_=None, budget_1=12.0, budget_all=8.0):
+    rows = cpu_loop(scenes, lasts, T0s, rs, budget_1, pose_solver, locals_)
+    per_frame = rows.sum(axis=1)
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nwork = max(1, min(ncores, 16))      # a 1-GPU box's CPU share is 16 cores whatever the host shows
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(3000 + i), str(budget_all), pose_solver],
+                              stdout=subprocess.PIPE, text=True) for i in range(nwork)]
+    outs = []
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        if p.returncode == 0 and o.strip():
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+    all_fps = float(sum(o["frames"] / o["busy_s"] for o in outs)) if outs else None
+    model = ""
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    what = {"pnp": "PnP RANSAC", "poseopt": "PoseOptimization", "motion_model": "Tracking::TrackWithMotionModel (align+match+pose under image_align)",
+            "track": "TrackWithMotionModel + TrackLocalMap (under search_by_projection)"}[pose_solver]
+    return {"value": float(len(rows) / (per_frame.sum() / 1e3)), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{len(rows)} VGA frame pairs after 2 warm-up, full step (ORB extract + ImageAlign + SearchByProjection + {what}), "
+                      f"1 thread; all-cores leg: {len(outs)} processes x {budget_all:.0f} s, one independent frame stream each",
+            "ms_per_frame_median": float(np.median(per_frame)), "ms_per_frame_p95": float(np.percentile(per_frame, 95)),
+            "stages_ms_median": {k: float(v) for k, v in zip(STAGES_CPU, np.median(rows, axis=0))},
+            "stages_ms_p95": {k: float(v) for k, v in zip(STAGES_CPU, np.percentile(rows, 95, axis=0))},
+            "all_cores": {"value": all_fps, "unit": "frames/s", "cores": len(outs), "host_cpus_visible": ncores, "cpu_model": model}}
+
+
+# ------------------------------------------------------------------------------------------------ PMC / VALU figures
+STAGE_KERNELS = {"pyramid": ["k_pyr_resize", "k_pyr_edges", "k_pyr_rows", "k_pyr_level", "k_pyr_fused"], "fast_nms": ["k_fast_cells"],
                  "select": ["k_select_level"], "blur": ["k_blur"], "orient_desc": ["k_orient_desc"], "image_align": ["k_align"],
-                 "search_by_projection": ["k_match"], "pnp_ransac": ["k_pnp"]}
+                 "search_by_projection": ["k_match"], "pnp_ransac": ["k_pnp"], "search_by_points": ["k_search_points"]}
 PMC_FRAMES = 1024       # frames per launch in the committed PMC passes (tools/run_profiles.sh: default batch)
-N_SIMD, CLK_GHZ = 1024, 2.4
 
 
 def pmc_for_stage(stage, batch):
-    """HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, MI355X_MICROARCH.md) and VALU issue
-    figures of the stage's kernels from the newest committed profiles/*pmc_summary*.json; (None, None) if absent.
-    PMC counters cannot be collected from inside this process; the passes are rocprofv3 runs of this same command."""
+    """HBM bytes per launch (FETCH_SIZE with the gfx950 correction + WRITE_SIZE, MI355X_MICROARCH.md) and VALU issue figures
+    of the stage's kernels from the newest committed profiles/*pmc_summary*.json; (None, None) if absent.  PMC counters
+    cannot be collected from inside this process; the passes are rocprofv3 runs of this same command."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary_b1024.json")))
     if not files:
@@ -136,6 +198,7 @@ def pmc_for_stage(stage, batch):
     d = json.load(open(files[-1]))
     tot, valu, dur = 0.0, 0.0, 0.0
     found = False
+
     def entry(name):      # templated kernels appear as "void k_align<4>"
         for key, val in d.items():
             if key == name or key.replace("void ", "").split("<")[0] == name:
@@ -154,35 +217,246 @@ def pmc_for_stage(stage, batch):
     if not found:
         return None, None
     sc = batch / PMC_FRAMES
-    min_ms = valu * sc / N_SIMD * 4 / (CLK_GHZ * 1e9) * 1e3      # one wave64 VALU instruction per 4 cycles per SIMD
-    return tot * sc, {"wave_insts_per_launch": valu * sc, "min_ms_at_full_issue": min_ms,
+    min_ms = valu * sc / N_SIMD * VALU_CYCLES / (CLK_GHZ * 1e9) * 1e3
+    return tot * sc, {"wave_insts_per_step": valu * sc, "cycles_per_inst": VALU_CYCLES, "min_ms_at_full_issue": min_ms,
                       "profiled_kernel_ms": dur * sc / 1e6, "source": os.path.basename(files[-1])}
 
 
+# ------------------------------------------------------------------------------------------------ the GPU workload
+class Workload:
+    """Everything one rank keeps resident, and the step bench.py times (tests/test_bench_step_gpu.py runs the same object)."""
+
+    def __init__(self, scenes, batch, device=0, pose_solver="pnp", orb_only=False, hamming=False, w=640, h=480, rank=0):
+        import sdslam_amd
+        from sdslam_amd import synth
+        from sdslam_amd.capi import DeviceBuffer
+        self.sd, self.synth = sdslam_amd, synth
+        self.B, self.w, self.h = batch, w, h
+        self.pose_solver, self.orb_only, self.hamming = pose_solver, orb_only, hamming
+        self.bounds = (0.0, float(w), 0.0, float(h))
+        self.K = (synth.FX, synth.FY, synth.CX, synth.CY)
+        B = batch
+        self.scenes = scenes
+        self.nu = nu = max(1, min(len(scenes), B))
+        self.idx = [i % nu for i in range(B)]
+        cur_frames = np.stack([scenes[i]["cur"] for i in self.idx])
+        self.d_cur = DeviceBuffer(cur_frames.nbytes)
+        self.d_cur.upload(cur_frames)
+        self.cur_frames_host = cur_frames
+        self.cur = sdslam_amd.ORBextractor(*CFG, w, h, B, device=device)
+        self.ref = sdslam_amd.ORBextractor(*CFG, w, h, B, device=device)
+        self.trk = sdslam_amd.Tracker(self.cur, self.ref, max_points=1000, max_batch=B, pnp_max_iterations=PNP["max_iterations"])
+        self.trk.set_camera(*self.K, 0.0, self.bounds)
+        # ---- untimed setup: what the previous tracking step leaves behind
+        ref_u = np.stack([s["ref"] for s in scenes[:nu]])
+        rk, rd, rn = self.ref.extract_batch(ref_u)                       # unique last frames first: their keypoints seed the map points
+        self.lasts_u = [synth.tracking_case(i, rk[i, :rn[i]], rd[i, :rn[i]]) for i in range(nu)]
+        if B > nu:
+            d_ref = DeviceBuffer(ref_u[0].nbytes * B)
+            d_ref.upload(np.stack([scenes[i]["ref"] for i in self.idx]))
+            self.ref.extract_batch_device(d_ref.ptr, B, w, h)
+            self.ref.sync()
+            d_ref.free()
+        self.trk.set_last(0, [self.lasts_u[i] for i in self.idx])
+        pert = synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04))   # motion-model prediction error
+        self.T0_u = [pert @ s["T_cur"] for s in scenes[:nu]]
+        self.T_ref = [scenes[i]["T_ref"] for i in self.idx]
+        self.T0 = [self.T0_u[i] for i in self.idx]
+        self.rs = synth.glibc_rand_stream(4 * PNP["max_iterations"])
+        self.trk.set_rand(0, np.tile(self.rs, (B, 1)))
+        self.trk.set_poses(0, self.T_ref, self.T0)         # last-frame poses + motion-model predictions (resident, like the frames)
+        self.locals_u = None
+        if pose_solver == "track" and not orb_only:        # the local map of every frame (UpdateLocalMap is the caller's)
+            ck, cd, cn = self.cur.extract_batch(np.stack([s_["cur"] for s_ in scenes[:nu]]))
+            self.locals_u = [{k: v[:1000] for k, v in synth.local_map_case(500 + i, ck[i, :cn[i]], cd[i, :cn[i]], scenes[i]["T_cur"]).items()}
+                             for i in range(nu)]
+            self.trk.set_local(0, [self.locals_u[i] for i in self.idx])
+        if hamming:
+            ones = np.ones((B, self.cur.cap), np.uint8)
+            self.trk.set_point_flags(0, ones, ones)
+        self.rec_ptr = [None, None]      # device record buffers (set by attach_records)
+        self.k = 0
+
+    def attach_records(self, ptr0, ptr1):
+        self.rec_ptr = [ptr0, ptr1]
+
+    def record_source(self):
+        return 4 if (self.orb_only or self.hamming) else RECORD_SOURCE[self.pose_solver]
+
+    def step(self):
+        """One pass of the hot path over the resident batch; ends with the pose records packed on the device."""
+        B, trk = self.B, self.trk
+        self.cur.extract_batch_device(self.d_cur.ptr, B, self.w, self.h)
+        if self.hamming:
+            trk.search_by_points(B, 0.75, True)
+        elif self.orb_only:
+            pass
+        elif self.pose_solver in ("motion_model", "track"):
+            trk.track_with_motion_model(B, th=8.0, mono=True, align_mode=0)
+            if self.pose_solver == "track":
+                trk.track_local_map(B, th=1.0)
+        else:
+            trk.align(B, 0)
+            trk.match(B, 8.0, True, True)
+            if self.pose_solver == "pnp":
+                trk.pnp(B, PNP["probability"], PNP["min_inliers"], PNP["max_iterations"], PNP["min_set"], PNP["epsilon"],
+                        PNP["th2"], PNP["max_iterations"])
+            else:
+                trk.pose_opt(B, 0)
+        if self.rec_ptr[0] is not None and not self.orb_only:
+            trk.pack_records(B, self.record_source(), self.rec_ptr[self.k % 2])
+        self.k += 1
+
+    def results(self):
+        """Host copies of what the last step left (align, matches, pose solve)."""
+        B, trk = self.B, self.trk
+        al = trk.get_align(0, B)
+        cm, nm = trk.get_matches(0, B)
+        if self.pose_solver == "pnp" or self.orb_only or self.hamming:
+            pn = trk.get_pnp(0, B)
+        elif self.pose_solver == "motion_model":
+            po, tw = trk.get_pose_opt(0, B), trk.get_tracked(0, B)
+            pn = dict(ok=tw["status"] == 2, n_inliers=tw["nmatches_map"], iterations=po["iterations"], N=po["n_initial"])
+        elif self.pose_solver == "track":
+            po, tl = trk.get_pose_opt(0, B), trk.get_local_map(0, B)
+            pn = dict(ok=tl["status"] == 2, n_inliers=tl["n_inliers"], iterations=po["iterations"], N=po["n_initial"])
+        else:
+            po = trk.get_pose_opt(0, B)
+            pn = dict(ok=po["n_inliers"] >= 10, n_inliers=po["n_inliers"], iterations=po["iterations"], N=po["n_initial"])
+        return al, cm, nm, pn
+
+
+def stress_legs(wl, steps=6):
+    """The cases the default scenes do not reach: ImageAlign from an identity prior (worst case of SURVEY C3),
+    PnP RANSAC on a planted 40 %-outlier match vector, and PnP RANSAC that can never accept (exactly minInliers exact
+    inliers: every refit fails the strict `>`), i.e. all 200 iterations for every frame."""
+    import torch
+    B, trk, synth = wl.B, wl.trk, wl.synth
+    out = {}
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        wl.cur.sync()
+        trk.get_tracked(0, 1)          # synchronises the tracking stream
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    # (a) identity prior: the whole step, alignment starts from I instead of the motion-model prediction
+    trk.set_poses(0, wl.T_ref, [np.eye(4)] * B)
+    dt = timed(wl.step, steps)
+    al = trk.get_align(0, B)
+    out["align_identity_prior"] = {"frames_per_s": B / dt, "ms_per_step": dt * 1e3, "mean_gn_iterations": float(al["iters"][:, :8].sum(axis=1).mean()),
+                                   "align_ok": int(al["ok"].sum())}
+    trk.set_poses(0, wl.T_ref, wl.T0)
+    # (b), (c): PnP alone on caller-supplied match vectors (sd_track_set_matches)
+    ck, cd, cn = wl.cur.download(0, wl.nu)
+    for name, kw, eps in (("pnp_outliers40", dict(n_match=300, outlier_frac=0.40, noise_px=0.5), PNP["epsilon"]),
+                          ("pnp_forced_200_iterations", dict(n_match=300, outlier_frac=0.0, n_exact_inliers=84), PNP["epsilon"])):
+        cases = [synth.planted_matches(900 + i, ck[i, :cn[i]], wl.scenes[i]["T_cur"], **kw) for i in range(wl.nu)]
+        trk.set_last(0, [cases[i][0] for i in wl.idx])
+        cmv = np.full((B, wl.cur.cap), -1, np.int32)
+        for b, i in enumerate(wl.idx):
+            cmv[b, :len(cases[i][1])] = cases[i][1]
+        trk.set_matches(0, cmv)
+        fn = lambda: trk.pnp(B, PNP["probability"], PNP["min_inliers"], PNP["max_iterations"], 4, eps, PNP["th2"], PNP["max_iterations"])  # noqa: E731
+        dt = timed(fn, steps)
+        g = trk.get_pnp(0, B)
+        out[name] = {"ms_per_launch": dt * 1e3, "frames": B, "mean_iterations": float(g["iterations"].mean()), "max_iterations": int(g["iterations"].max()),
+                     "returned": int(g["ok"].sum()), "refined": int(g["refined"].sum()), "mean_inliers": float(g["n_inliers"].mean())}
+    trk.set_last(0, [wl.lasts_u[i] for i in wl.idx])
+    return out
+
+
+def h2d_leg(wl, steps=4):
+    """Frames in page-locked host memory, uploaded at the start of every step (synchronous copy, then the step)."""
+    import torch
+    from sdslam_amd.capi import pinned_array, lib, _p
+    pf, owner = pinned_array(wl.cur_frames_host.shape)
+    pf[...] = wl.cur_frames_host
+
+    def once():
+        lib().sd_dev_upload(wl.d_cur.ptr, _p(pf), pf.nbytes)
+        wl.step()
+    once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        once()
+    wl.cur.sync()
+    wl.trk.get_tracked(0, 1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"frames_per_s": wl.B / dt, "ms_per_step": dt * 1e3, "upload_GBps": pf.nbytes / dt / 1e9,
+            "note": "synchronous upload from page-locked memory, not overlapped with the previous step"}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N child ranks (fresh processes, nothing GPU-related has run in
+    this one), wait for all, fail if any fails."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    sys.exit(rc)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker_main(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step")
-    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic scenes (tiled to --batch)")
+    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic scenes (tiled to --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--orb-only", action="store_true", help="time ORB extraction alone (configs[1] without tracking)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stress / h2d legs (profiling runs)")
+    ap.add_argument("--orb-only", action="store_true", help="time ORB extraction alone (configs[1] without matching)")
+    ap.add_argument("--hamming", action="store_true", help="BASELINE configs[1]: ORB extract + brute-force Hamming match "
+                                                            "(ORBmatcher::SearchByPoints, 1000 x 1000 per frame pair)")
     ap.add_argument("--res", default="640x480", help="frame size WxH (BASELINE configs[4] uses 1280x720 frames; the metric is quoted at 640x480)")
     ap.add_argument("--pose-solver", choices=["pnp", "poseopt", "motion_model", "track"], default="pnp",
                     help="pnp: PnPsolver RANSAC (the BASELINE metric); poseopt: Optimizer::PoseOptimization, the pose solve the reference's "
-                         "TrackWithMotionModel really calls (SURVEY D1) -- reported under the same metric name with config.pose_solver set; "
-                         "motion_model: the whole Tracking::TrackWithMotionModel as one call (retry search, failure exits, outlier discard); "
+                         "TrackWithMotionModel really calls (SURVEY D1); motion_model: the whole Tracking::TrackWithMotionModel as one call; "
                          "track: motion_model followed by Tracking::TrackLocalMap over a ~1000-point local map per frame")
     args = ap.parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return spawn_ranks(args)
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world} (launch one rank per GPU, or run without a launcher)")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     global W, H, BOUNDS
     W, H = (int(v) for v in args.res.lower().split("x"))
     BOUNDS = (0.0, float(W), 0.0, float(H))
+    B = args.batch
+
+    # ---- scenes: generated on the host cores BEFORE anything touches the GPU (fork pool)
+    nu = max(1, min(args.unique, B))
+    import multiprocessing as mp
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4
+    nproc = max(1, min(16 // max(1, min(world, 8)), ncpu, nu))
+    if nproc > 1:
+        with mp.get_context("fork").Pool(nproc) as pool:
+            scenes = make_cases(nu, 1000 + 100 * rank, W, H, pool)
+    else:
+        scenes = make_cases(nu, 1000 + 100 * rank, W, H)
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -190,51 +464,25 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
 
     import sdslam_amd
-    from sdslam_amd import synth
-    from sdslam_amd.capi import DeviceBuffer
+    from sdslam_amd import dist_util
+    wl = Workload(scenes, B, local_rank, args.pose_solver, args.orb_only, args.hamming, W, H, rank)
+    cur, trk = wl.cur, wl.trk
+    # per-frame records: written by the last tracking kernel (double-buffered), gathered from there
+    rec = [torch.zeros((B, dist_util.RECORD_F64), dtype=torch.float64, device=dev) for _ in range(2)]
+    gathered = [torch.zeros((B * world, dist_util.RECORD_F64), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    wl.attach_records(rec[0].data_ptr(), rec[1].data_ptr())
+    stream = torch.cuda.current_stream().cuda_stream
 
-    B = args.batch
-    K = (synth.FX, synth.FY, synth.CX, synth.CY)
-    nu = max(1, min(args.unique, B))
-    scenes = make_cases(nu, 1000 + 100 * rank, W, H)
-    idx = [i % nu for i in range(B)]
-    cur_frames = np.stack([scenes[i]["cur"] for i in idx])
-    ref_frames = np.stack([scenes[i]["ref"] for i in idx])
-    d_cur = DeviceBuffer(cur_frames.nbytes)
-    d_cur.upload(cur_frames)
-
-    cur = sdslam_amd.ORBextractor(*CFG, W, H, B, device=local_rank)
-    ref = sdslam_amd.ORBextractor(*CFG, W, H, B, device=local_rank)
-    trk = sdslam_amd.Tracker(cur, ref, max_points=1000, max_batch=B, pnp_max_iterations=PNP["max_iterations"])
-    trk.set_camera(*K, 0.0, BOUNDS)
-
-    # ---- untimed setup: what the previous tracking step leaves behind
-    rk, rd, rn = ref.extract_batch(ref_frames)                       # last frames' pyramids stay resident
-    lasts_u = [synth.tracking_case(i, rk[i, :rn[i]], rd[i, :rn[i]]) for i in range(nu)]
-    trk.set_last(0, [lasts_u[i] for i in idx])
-    pert = synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04))   # motion-model prediction error
-    T0_u = [pert @ s["T_cur"] for s in scenes]
-    T_ref = [scenes[i]["T_ref"] for i in idx]
-    T0 = [T0_u[i] for i in idx]
-    rs = synth.glibc_rand_stream(4 * PNP["max_iterations"])
-    trk.set_rand(0, np.tile(rs, (B, 1)))
-
-    def step():
-        cur.extract_batch_device(d_cur.ptr, B, W, H)
-        if not args.orb_only and args.pose_solver in ("motion_model", "track"):
-            trk.track_with_motion_model(B, th=8.0, mono=True, align_mode=0)
-            if args.pose_solver == "track":
-                trk.track_local_map(B, th=1.0)
-        elif not args.orb_only:
-            trk.align(B, 0)
-            trk.match(B, 8.0, True, True)
-            if args.pose_solver == "pnp":
-                trk.pnp(B, PNP["probability"], PNP["min_inliers"], PNP["max_iterations"], PNP["min_set"], PNP["epsilon"],
-                        PNP["th2"], PNP["max_iterations"])
-            else:
-                trk.pose_opt(B, 0)
+    def full_step(k):
+        if dist is not None:
+            trk.stream_fence(stream, 1)          # the pack of this step must not overwrite a buffer the last gather still reads
+        wl.step()
+        if dist is not None and not args.orb_only:
+            trk.stream_fence(stream, 0)          # the collective waits for the records
+            dist_util.all_gather_records(rec[k % 2], gathered[k % 2], dist)
 
     def barrier():
         torch.cuda.synchronize()
@@ -242,96 +490,97 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    trk.set_poses(0, T_ref, T0)         # last-frame poses + motion-model predictions (resident, like the frames)
-    locals_u = None
-    if args.pose_solver == "track" and not args.orb_only:      # the local map of every frame (UpdateLocalMap is the caller's)
-        ck, cd, cn = cur.extract_batch(np.stack([s_["cur"] for s_ in scenes]))
-        locals_u = [{k: v[:1000] for k, v in synth.local_map_case(500 + i, ck[i, :cn[i]], cd[i, :cn[i]], scenes[i]["T_cur"]).items()}
-                    for i in range(nu)]
-        trk.set_local(0, [locals_u[i] for i in idx])
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        full_step(k)
     cur.sync()
     cur.set_profiling(True)
     trk.set_profiling(True)
+    wl.k = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()                          # every step re-aligns from the predicted pose (Tprior is not overwritten)
+    for k in range(args.steps):
+        full_step(k)                    # every step re-aligns from the predicted pose (Tprior is not overwritten)
+    cur.sync()
+    trk.get_tracked(0, 1)               # host-side wait for the tracking stream (its work is not on torch's streams)
     barrier()
     dt = time.perf_counter() - t0
     orb_ms = cur.stage_ms()
     trk_ms = trk.stage_ms() if not args.orb_only else np.zeros(3, np.float32)
-    if args.pose_solver == "track" and not args.orb_only:
+    if args.pose_solver == "track" and not args.orb_only and not args.hamming:
         trk_ms[1:] *= 2      # the timers average per call; search and PoseOptimization run twice per step here
     cur.set_profiling(False)
     trk.set_profiling(False)
-
-    # ---- results: fixed-size per-frame records (pose + counts), all-gathered across ranks
-    al = trk.get_align(0, B)
-    if args.pose_solver == "pnp" or args.orb_only:
-        pn = trk.get_pnp(0, B)
-    elif args.pose_solver == "motion_model":
-        po, tw = trk.get_pose_opt(0, B), trk.get_tracked(0, B)
-        pn = dict(ok=tw["status"] == 2, n_inliers=tw["nmatches_map"], iterations=po["iterations"], N=po["n_initial"])
-    elif args.pose_solver == "track":
-        po, tl = trk.get_pose_opt(0, B), trk.get_local_map(0, B)
-        pn = dict(ok=tl["status"] == 2, n_inliers=tl["n_inliers"], iterations=po["iterations"], N=po["n_initial"])
-    else:
-        po = trk.get_pose_opt(0, B)
-        pn = dict(ok=po["n_inliers"] >= 10, n_inliers=po["n_inliers"], iterations=po["iterations"], N=po["n_initial"])
-    cm, nm = trk.get_matches(0, B)
-    from sdslam_amd import dist_util
-    rec = dist_util.pack_records([t.T.ravel() for t in al["T"]], al["ok"], nm, pn["n_inliers"], pn["ok"])
-    dev = torch.device("cuda", local_rank)
     dt = dist_util.max_over_ranks(dt, dist, dev)                      # MAX over ranks
-    all_rec = dist_util.gather_records(rec, B * world, dist, dev)     # the only inter-GPU traffic
-    assert all_rec.shape == (B * world, dist_util.RECORD_F64)
+
+    # ---- check what was gathered: every rank's block of the last step equals that rank's own records
+    last = (args.steps - 1) % 2
+    if world > 1 and not args.orb_only:
+        mine = gathered[last][rank * B:(rank + 1) * B]
+        assert torch.equal(mine, rec[last]), "gathered records differ from the local ones"
+    rec_host = rec[last].cpu().numpy()
 
     if rank == 0:
+        al, cm, nm, pn = wl.results()
+        if not args.orb_only and not args.hamming:      # the device-packed records equal the per-stage read-outs
+            assert np.array_equal(rec_host[:, 17], nm.astype(np.float64)) and np.array_equal(rec_host[:, 18], pn["n_inliers"].astype(np.float64))
         total_frames = B * args.steps * world
-        names = cur.stage_names() + ["image_align", "search_by_projection", "pnp_ransac" if args.pose_solver == "pnp" else "pose_optimization"]
+        solver_name = "pnp_ransac" if args.pose_solver == "pnp" else "pose_optimization"
+        names = cur.stage_names() + ["image_align", "search_by_points" if args.hamming else "search_by_projection", solver_name]
         stage_ms = np.concatenate([orb_ms, trk_ms])
         sbytes = list(cur.stage_bytes())
         # algorithmic bytes of the tracking stages, from what this run actually did
-        P = float(np.mean([min(300, int(l["valid"].sum())) for l in lasts_u]))
+        P = float(np.mean([min(300, int(l["valid"].sum())) for l in wl.lasts_u]))
         its = float(al["iters"][:, :8].sum(axis=1).mean())
         lv = sdslam_amd.plan_info(*CFG, W, H)["levels"]
         px_l = float(sum(lv[l, 0] * lv[l, 1] for l in (2, 3, 4)))
         sbytes += [its * P * (25 + 64) + 2 * px_l,                       # ImageAlign
-                   P * (32 + 10 * 32),                                   # windowed Hamming (c ~ 10)
+                   2 * 1000 * 32 if args.hamming else P * (32 + 10 * 32),   # brute force: compulsory descriptor reads; windowed: c ~ 10
                    float(pn["iterations"].mean()) * (4 * 20 + float(pn["N"].mean()) * 24)]   # PnP
         dom = int(np.argmax(stage_ms))
         achieved = sbytes[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
         traffic, valu = pmc_for_stage(names[dom], B)
-        terr = float(np.mean([np.abs(al["T"][b][:3, 3] - scenes[idx[b]]["T_cur"][:3, 3]).max() for b in range(min(B, nu))]))
+        terr = float(np.mean([np.abs(al["T"][b][:3, 3] - scenes[wl.idx[b]]["T_cur"][:3, 3]).max() for b in range(min(B, nu))]))
+        if args.orb_only:
+            workload = f"ORB extract only (BASELINE configs[1] without matching), {W}x{H}"
+        elif args.hamming:
+            workload = (f"BASELINE configs[1]: {W}x{H} 8-level x1.2 pyramid, 1000 kp, ORB extract + brute-force Hamming match "
+                        "(ORBmatcher::SearchByPoints, 1000 x 1000 per frame pair, nnratio 0.75, orientation check)")
+        else:
+            workload = (f"BASELINE configs[3] at the configs[1] pyramid: {W}x{H}, 8-level x1.2, 1000 kp; ORB extract + ImageAlign (levels 4,3,2) + "
+                        "SearchByProjection + " + ("PnP RANSAC (maxIts 200; iterations actually run: tracking.mean_pnp_iterations)"
+                                                   if args.pose_solver == "pnp" else "Optimizer::PoseOptimization (g2o LM, 4x10 its)") +
+                        (", as one Tracking::TrackWithMotionModel call" if args.pose_solver in ("motion_model", "track") else "") +
+                        (" + Tracking::TrackLocalMap (th 1, <=1000 local points)" if args.pose_solver == "track" else ""))
         line = {
             "metric": "tracked frames/sec (ORB+ImageAlign+PnP) at 640x480, 1000 kp",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": (f"ORB extract only (BASELINE configs[1] without matching), {W}x{H}" if args.orb_only else
-                                    f"BASELINE configs[3] at the configs[1] pyramid: {W}x{H}, 8-level x1.2, 1000 kp; "
-                                    "ORB extract + ImageAlign (levels 4,3,2) + SearchByProjection + " +
-                                    ("PnP RANSAC 200 its" if args.pose_solver == "pnp" else "Optimizer::PoseOptimization (g2o LM, 4x10 its)") +
-                                    (", as one Tracking::TrackWithMotionModel call" if args.pose_solver in ("motion_model", "track") else "") +
-                                    (" + Tracking::TrackLocalMap (th 1, <=1000 local points)" if args.pose_solver == "track" else "")),
-                       "pose_solver": args.pose_solver,
-                       "frames_per_gpu_per_step": B, "unique_scenes": nu, "inputs": "resident in HBM",
-                       "pose_records": "all-gathered over RCCL" if world > 1 else "single GPU"},
+            "config": {"workload": workload, "pose_solver": args.pose_solver,
+                       "frames_per_gpu_per_step": B, "unique_scenes": nu, "inputs": "resident in HBM", "timed_region_s": dt,
+                       "pose_records": ("all-gathered over RCCL every step inside the timed region, straight from the device buffer the "
+                                        "last tracking kernel wrote") if world > 1 else "packed on the device every step (single GPU: no collective)"},
             "stages_ms_per_step": {nm_: float(ms) for nm_, ms in zip(names, stage_ms)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_frame": float(sbytes[dom]), "ms_per_step": float(stage_ms[dom]),
-                         "note": "integer/byte kernel limited by VALU issue, not HBM (DESIGN.md section 6); traffic = HBM bytes "
-                                 "per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/), scaled to this batch",
-                         "valu_issue": valu},
+                         "note": "integer/byte kernel limited by vector-ALU issue, not HBM (DESIGN.md section 6); traffic = HBM bytes per "
+                                 "step from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/), scaled to this batch",
+                         "valu": valu,
+                         "valu_frac": (valu["min_ms_at_full_issue"] / float(stage_ms[dom])) if valu else None},
             "tracking": {"align_ok": int(al["ok"].sum()), "mean_gn_iterations": its, "mean_matches": float(nm.mean()),
-                         "pnp_ok": int(pn["ok"].sum()), "mean_pnp_inliers": float(pn["n_inliers"].mean()),
+                         "pnp_ok": int(np.asarray(pn["ok"]).sum()), "mean_pnp_inliers": float(pn["n_inliers"].mean()),
                          "mean_pnp_iterations": float(pn["iterations"].mean()), "align_translation_err_m": terr},
         }
-        if not args.no_cpu_baseline and world == 1 and not args.orb_only:
-            line["cpu_baseline"] = cpu_baseline(scenes, lasts_u, T0_u, rs, pose_solver=args.pose_solver, locals_=locals_u)
+        if args.hamming:
+            m12, n12 = trk.get_point_matches(0, B)
+            line["tracking"]["mean_point_matches"] = float(n12.mean())
+        if world == 1 and not args.orb_only and not args.hamming and not args.no_extras:
+            line["stress"] = stress_legs(wl)
+            line["h2d_inclusive"] = h2d_leg(wl)
+        if not args.no_cpu_baseline and world == 1 and not args.orb_only and not args.hamming:
+            line["cpu_baseline"] = cpu_baseline(scenes[:min(nu, 8)], wl.lasts_u[:min(nu, 8)], wl.T0_u[:min(nu, 8)], wl.rs, pose_solver=args.pose_solver,
+                                                locals_=wl.locals_u)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line, default=float))

@@ -287,6 +287,14 @@ int sd_track_debug_read(sd_track* h, int which, int frame, void* out, size_t byt
  * indices in the reference's vIndices order; grid_counts (may be NULL) = mGrid[x][y].size(), [64][48]. */
 int sd_track_debug_features_in_area(sd_track* h, int frame, float x, float y, float r, int min_level, int max_level,
                                     int32_t* indices, int cap, int32_t* n_out, int32_t* grid_counts);
+/* Batched-frames mode across GPUs: the fixed-size per-frame result records -- the only data that leaves a GPU.
+ * sd_track_pack_records queues, behind the tracking stages, a kernel that writes n_frames x 20 doubles {pose 4x4
+ * column-major, ImageAlign ok, nmatches, pose-solver inliers, pose-solver ok} into a caller-owned DEVICE buffer; source =
+ * 0 PnPsolver / 1 PoseOptimization / 2 TrackWithMotionModel / 3 TrackLocalMap / 4 ImageAlign only.
+ * sd_track_stream_fence orders the tracking stream against a caller's hipStream_t (the stream of its RCCL collective):
+ * direction 0 = that stream waits for the tracking stream, 1 = the tracking stream waits for that stream. */
+int sd_track_pack_records(sd_track* h, int n_frames, int source, void* d_records);
+int sd_track_stream_fence(sd_track* h, void* hip_stream, int direction);
 int sd_track_set_profiling(sd_track* h, int on);
 int sd_track_stage_ms(sd_track* h, float* ms_out /* [0]=align, [1]=match, [2]=pnp */, int cap);
 

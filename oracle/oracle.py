@@ -76,6 +76,13 @@ class OrbOracle:
         assert n <= self.cap
         return kps[:n].copy(), desc[:n].copy()
 
+    def stage_ns(self):
+        """Wall-clock ns of the last extract() per stage: pyramid, FAST+NMS, select, IC_Angle, blur, rBRIEF."""
+        out = np.zeros(6)
+        self.L.orc_orb_stage_ns.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_orb_stage_ns(self.h, _p(out))
+        return out
+
     def level(self, l, padded=False):
         w, h = C.c_int(), C.c_int()
         assert self.L.orc_orb_level_info(self.h, l, C.byref(w), C.byref(h)) == 0

@@ -14,6 +14,7 @@
 #include "cvlite.h"
 #include "oracle_api.h"
 #include <cassert>
+#include <chrono>
 
 namespace orc {
 
@@ -188,7 +189,9 @@ struct ORBextractor {
           if (x0 < 0 || y0 < 0 || x1 > img.cols || y1 > img.rows || x1 < x0 || y1 < y0) continue;
           View cellImage = img.roi(x0, y0, x1 - x0, y1 - y0);
           cellKeyPoints[i][j].reserve(std::max(nfeaturesCell, 0) * 5);
+          const double tf = now_ns();
           FAST(cellImage, cellKeyPoints[i][j], thFAST, true);
+          stage_ns[1] += now_ns() - tf;
 
           const int nKeys = cellKeyPoints[i][j].size();
           nTotal[i][j] = nKeys;
@@ -249,10 +252,12 @@ struct ORBextractor {
         keypoints.resize(nDesiredFeatures);
       }
     }
+    const double ta = now_ns();
     for (int level = 0; level < nlevels; ++level) {
       View img = pyr[level].roi();
       for (auto& kp : allKeypoints[level]) kp.angle = IC_Angle(img, kp.x, kp.y);
     }
+    stage_ns[3] = now_ns() - ta;
   }
 
   // src/ORBextractor.cc:106-143
@@ -275,13 +280,25 @@ struct ORBextractor {
   }
 
   // src/ORBextractor.cc:620-678
+  // wall-clock per stage of the last extract() (bench.py's cpu_baseline: SURVEY §8d asks for per-stage medians):
+  // 0 pyramid, 1 FAST + NMS, 2 quota loop + retainBest + assembly, 3 IC_Angle, 4 GaussianBlur, 5 rBRIEF
+  double stage_ns[6] = {0, 0, 0, 0, 0, 0};
+  static double now_ns() {
+    return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+
   int extract(const View& image, std::vector<KeyPoint>& keypointsOut, std::vector<uint8_t>& descriptors) {
     keypointsOut.clear();
     descriptors.clear();
+    for (double& v : stage_ns) v = 0;
     if (image.cols <= 0 || image.rows <= 0) return 0;
+    double t0 = now_ns();
     ComputePyramid(image);
+    stage_ns[0] = now_ns() - t0;
     std::vector<std::vector<KeyPoint>> allKeypoints;
+    t0 = now_ns();
     ComputeKeyPoints(allKeypoints);
+    stage_ns[2] = now_ns() - t0 - stage_ns[1] - stage_ns[3];
     lastLevelKeypoints = allKeypoints;
     lastBlurred.assign(nlevels, {});
 
@@ -301,8 +318,12 @@ struct ORBextractor {
       View wv{work.data(), L.w, L.h, L.w};
       View src = L.roi();
       for (int y = 0; y < L.h; y++) memcpy(wv.ptr(y), src.ptr(y), L.w);  // clone(): compact
+      const double tb = now_ns();
       gaussianBlur7(wv, wv);
+      const double td = now_ns();
       for (int i = 0; i < n; i++) computeOrbDescriptor(keypoints[i], wv, pattern.data(), &descriptors[(size_t)(offset + i) * 32]);
+      stage_ns[4] += td - tb;
+      stage_ns[5] += now_ns() - td;
       offset += n;
       if (level != 0) {
         float scale = mvScaleFactor[level];
@@ -353,6 +374,10 @@ int orc_orb_extract(void* h, const uint8_t* img, int w, int hh, int stride, void
   if (kps_out && m > 0) memcpy(kps_out, kps.data(), (size_t)m * sizeof(KeyPoint));
   if (desc_out && m > 0) memcpy(desc_out, desc.data(), (size_t)m * 32);
   return n;
+}
+
+void orc_orb_stage_ns(void* h, double* out6) {
+  for (int i = 0; i < 6; i++) out6[i] = ((ORBextractor*)h)->stage_ns[i];
 }
 
 // pyramid level access after extract(): padded=1 -> whole (w+38)x(h+38) buffer

@@ -587,6 +587,16 @@ class Tracker:
                                                       _p(grid) if want_grid else None))
         return (idx[:n.value].copy(), grid) if want_grid else idx[:n.value].copy()
 
+    def pack_records(self, n_frames, source, d_ptr):
+        """Queue the packing of the batch's result records (n_frames x 20 f64) into device memory at `d_ptr`."""
+        self.L.sd_track_pack_records.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _check(self.L.sd_track_pack_records(self.h, n_frames, int(source), C.c_void_p(d_ptr)))
+
+    def stream_fence(self, stream_ptr, direction):
+        """direction 0: the caller's stream waits for the tracking stream; 1: the tracking stream waits for the caller's."""
+        self.L.sd_track_stream_fence.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _check(self.L.sd_track_stream_fence(self.h, C.c_void_p(stream_ptr) if stream_ptr else None, int(direction)))
+
     def set_profiling(self, on=True):
         _check(self.L.sd_track_set_profiling(self.h, int(on)))
 

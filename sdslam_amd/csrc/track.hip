@@ -47,10 +47,40 @@ struct sd_track {
   // (ev_extract_done) and marks the sets it read (ev_set_free).
   hipStream_t pnp_stream = nullptr;
   bool profiling = false;
+  hipEvent_t ev_fence = nullptr;   // sd_track_stream_fence
   static const int kRing = 128;
   hipEvent_t ev[kRing][6] = {};
   int ev_calls[3] = {0, 0, 0};
 };
+
+// Per-frame result record (the only data that crosses xGMI in the batched-frames mode), 20 doubles:
+// pose 4x4 column-major | ImageAlign ok | nmatches | pose-solver inliers | pose-solver ok
+//   source 0: PnPsolver (pose = Tcw it returned, zeros for an empty Mat)   1: PoseOptimization (ok = nGood >= 10)
+//   source 2: TrackWithMotionModel (inliers = nmatchesMap, ok = tracked)   3: TrackLocalMap (mnMatchesInliers, tracked)
+//   source 4: ImageAlign only (pose = the aligned pose)
+__global__ void k_pack_records(TrackBuffers tb, int source, int n_frames, double* __restrict__ out) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  double* r = out + (size_t)f * 20;
+  if (source == 0) {
+    const float* T = tb.pnp_T + (size_t)f * 16;   // row-major CV_32F
+    for (int c = 0; c < 4; c++)
+      for (int rr = 0; rr < 4; rr++) r[c * 4 + rr] = (double)T[rr * 4 + c];
+  } else {
+    const double* T = (source == 4 ? tb.Tcur : tb.po_T) + (size_t)f * 16;
+    for (int i = 0; i < 16; i++) r[i] = T[i];
+  }
+  r[16] = (double)tb.al_ok[f];
+  r[17] = (double)tb.n_matches[f];
+  double inl = 0, ok = 0;
+  if (source == 0) { inl = tb.pnp_info[(size_t)f * 8 + 1]; ok = tb.pnp_info[(size_t)f * 8]; }
+  else if (source == 1) { inl = tb.po_info[(size_t)f * 8 + 5]; ok = inl >= 10; }
+  else if (source == 2) { inl = tb.tw_info[(size_t)f * 4 + 2]; ok = tb.tw_info[(size_t)f * 4] == 2; }
+  else if (source == 3) { inl = tb.tl_info[(size_t)f * 4 + 2]; ok = tb.tl_info[(size_t)f * 4] == 2; }
+  else { ok = tb.al_ok[f]; }
+  r[18] = inl;
+  r[19] = ok;
+}
 
 template <typename T>
 static int dalloc(sd_track* h, T** p, size_t count) {
@@ -223,6 +253,7 @@ void sd_track_destroy(sd_track* h) {
   if (h->cur && h->cur->stream) (void)hipStreamSynchronize(h->cur->stream);
   if (h->pnp_stream) (void)hipStreamDestroy(h->pnp_stream);
   for (void* p : h->allocs) (void)hipFree(p);
+  if (h->ev_fence) (void)hipEventDestroy(h->ev_fence);
   for (int r = 0; r < sd_track::kRing; r++)
     for (int i = 0; i < 6; i++)
       if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
@@ -922,6 +953,36 @@ int sd_track_debug_features_in_area(sd_track* h, int frame, float x, float y, fl
   SD_REQUIRE(n <= cap, SD_ERR_CAPACITY, "indices array too small");
   std::memcpy(indices, host.data(), (size_t)n * 4);
   if (grid_counts) std::memcpy(grid_counts, host.data() + h->kp_cap + 1, 64 * 48 * 4);
+  return SD_OK;
+}
+
+// The batch's result records into a caller-owned DEVICE buffer (n_frames x 20 doubles), queued on the tracking stream
+// behind the stages that produce them: no host round trip between the last tracking kernel and the collective that
+// gathers the records.
+int sd_track_pack_records(sd_track* h, int n_frames, int source, void* d_records) {
+  SD_REQUIRE(h && d_records, SD_ERR_INVALID_ARG, "NULL argument");
+  SD_REQUIRE(n_frames >= 1 && n_frames <= h->max_batch && source >= 0 && source <= 4, SD_ERR_INVALID_ARG, "bad n_frames / source");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_pack_records, dim3((n_frames + 255) / 256), dim3(256), 0, h->pnp_stream, h->tb, source, n_frames, (double*)d_records);
+  SD_HIP_CHECK(hipGetLastError());
+  return SD_OK;
+}
+
+// Ordering against a caller's HIP stream (the stream its RCCL collectives run on).  direction 0: `hip_stream` waits for
+// everything queued on the tracking stream so far (collective after the records are packed); 1: the tracking stream waits
+// for everything queued on `hip_stream` so far (the next pack must not overwrite a buffer a collective is still reading).
+int sd_track_stream_fence(sd_track* h, void* hip_stream, int direction) {
+  SD_REQUIRE(h && (direction == 0 || direction == 1), SD_ERR_INVALID_ARG, "bad arguments");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  hipStream_t ext = (hipStream_t)hip_stream;   // NULL = the legacy default stream
+  if (!h->ev_fence) SD_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fence, hipEventDisableTiming));
+  if (direction == 0) {
+    SD_HIP_CHECK(hipEventRecord(h->ev_fence, h->pnp_stream));
+    SD_HIP_CHECK(hipStreamWaitEvent(ext, h->ev_fence, 0));
+  } else {
+    SD_HIP_CHECK(hipEventRecord(h->ev_fence, ext));
+    SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, h->ev_fence, 0));
+  }
   return SD_OK;
 }
 

@@ -42,6 +42,15 @@ def gather_records(rec: np.ndarray, n_total: int, dist=None, device=None) -> np.
     return np.concatenate(parts, 0)
 
 
+def all_gather_records(rec_t, out_t, dist):
+    """The per-step collective of the batched-frames mode: every rank's [B, RECORD_F64] f64 block -> [world * B, RECORD_F64],
+    rank-major, tensor to tensor (device memory with nccl/RCCL; the same call runs on CPU tensors with gloo).  Equal shard
+    sizes (weak scaling: B frames per GPU); ragged shards go through gather_records."""
+    assert out_t.shape[0] == rec_t.shape[0] * dist.get_world_size() and out_t.shape[1:] == rec_t.shape[1:]
+    dist.all_gather_into_tensor(out_t, rec_t)
+    return out_t
+
+
 def max_over_ranks(value: float, dist=None, device=None) -> float:
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return value

@@ -140,6 +140,33 @@ def keyframe_case(kps, desc, T_kf, max_points=300):
                 angle=kps["angle"].astype(np.float32).copy(), obs=np.ones(n, np.int32))
 
 
+def planted_matches(seed, kps, T_cw, n_match, outlier_frac, noise_px=0.0, n_exact_inliers=None):
+    """A match vector the tracker did NOT produce (PnPsolver / PoseOptimization take any vpMapPointMatches): keypoint i of the
+    current frame is paired with map point i, whose world position is the back-projection of the keypoint at a random depth
+    under the true pose T_cw (+ pixel noise) -- or a gross outlier.
+    Returns (last, cm, truth): `last` = dict for Tracker.set_last / the oracle (one map point per keypoint slot), cm[i] = i for
+    the n_match chosen keypoints else -1, truth[i] = True where the pair is a planted inlier."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = len(kps)
+    chosen = np.sort(rng.choice(n, size=n_match, replace=False))
+    n_in = int(round(n_match * (1.0 - outlier_frac))) if n_exact_inliers is None else n_exact_inliers
+    inl = np.zeros(n, bool)
+    inl[rng.choice(chosen, size=n_in, replace=False)] = True
+    R, t = T_cw[:3, :3], T_cw[:3, 3]
+    xy = np.stack([kps["x"], kps["y"]], 1).astype(np.float64)
+    xy_n = xy + rng.normal(size=xy.shape) * noise_px
+    z = rng.uniform(1.0, 5.0, n)
+    Xc = np.stack([(xy_n[:, 0] - CX) / FX * z, (xy_n[:, 1] - CY) / FY * z, z], 1)
+    Xw = (Xc - t) @ R                       # R^T (Xc - t)
+    bad = ~inl
+    Xw[bad] = rng.uniform(-2.0, 2.0, size=(int(bad.sum()), 3)) + np.array([0, 0, 3.0])
+    cm = np.full(n, -1, np.int32)
+    cm[chosen] = chosen
+    last = dict(valid=np.ones(n, np.uint8), Xw=np.ascontiguousarray(Xw), desc=np.zeros((n, 32), np.uint8),
+                octave=kps["octave"].astype(np.int32).copy(), angle=kps["angle"].astype(np.float32).copy(), obs=np.ones(n, np.int32))
+    return last, cm, inl & (cm >= 0)
+
+
 def glibc_rand_stream(n, seed=1):
     """n raw rand() values of glibc's TYPE_3 additive-feedback generator seeded with `seed`.
     The reference never seeds: SD_SLAM::Random draws from the default seed-1 state (reference

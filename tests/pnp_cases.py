@@ -10,28 +10,7 @@ from sdslam_amd import synth
 K = (synth.FX, synth.FY, synth.CX, synth.CY)
 
 
-def planted(seed, kps, T_cw, n_match, outlier_frac, noise_px=0.0, n_exact_inliers=None):
-    """Returns (last, cm, truth): `last` = dict for Tracker.set_last / the oracle (one map point per keypoint slot), cm[i] = i for
-    the n_match chosen keypoints else -1, truth[i] = True where the pair is a planted inlier."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    n = len(kps)
-    chosen = np.sort(rng.choice(n, size=n_match, replace=False))
-    n_in = int(round(n_match * (1.0 - outlier_frac))) if n_exact_inliers is None else n_exact_inliers
-    inl = np.zeros(n, bool)
-    inl[rng.choice(chosen, size=n_in, replace=False)] = True
-    R, t = T_cw[:3, :3], T_cw[:3, 3]
-    xy = np.stack([kps["x"], kps["y"]], 1).astype(np.float64)
-    xy_n = xy + rng.normal(size=xy.shape) * noise_px
-    z = rng.uniform(1.0, 5.0, n)
-    Xc = np.stack([(xy_n[:, 0] - K[2]) / K[0] * z, (xy_n[:, 1] - K[3]) / K[1] * z, z], 1)
-    Xw = (Xc - t) @ R                       # R^T (Xc - t)
-    bad = ~inl
-    Xw[bad] = rng.uniform(-2.0, 2.0, size=(int(bad.sum()), 3)) + np.array([0, 0, 3.0])
-    cm = np.full(n, -1, np.int32)
-    cm[chosen] = chosen
-    last = dict(valid=np.ones(n, np.uint8), Xw=np.ascontiguousarray(Xw), desc=np.zeros((n, 32), np.uint8),
-                octave=kps["octave"].astype(np.int32).copy(), angle=kps["angle"].astype(np.float32).copy(), obs=np.ones(n, np.int32))
-    return last, cm, inl & (cm >= 0)
+planted = synth.planted_matches
 
 
 def oracle_solver(O, kps, sigma2, last, cm):

@@ -30,6 +30,15 @@ for f in range(lo, hi):
 rec = dist_util.pack_records([r[0] for r in recs], [r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs], [r[4] for r in recs])
 allrec = dist_util.gather_records(rec, N, dist)
 tmax = dist_util.max_over_ranks(1.0 + rank, dist)
+# the per-step collective bench.py issues inside its timed region (tensor to tensor; device tensors over RCCL there)
+B = 4
+mine = torch.arange(B * dist_util.RECORD_F64, dtype=torch.float64).reshape(B, -1) + 1000.0 * rank
+both = torch.zeros((B * world, dist_util.RECORD_F64), dtype=torch.float64)
+for step in range(3):        # reused buffers, like the double-buffered records of the bench
+    dist_util.all_gather_records(mine + step, both, dist)
+    for r in range(world):
+        exp = torch.arange(B * dist_util.RECORD_F64, dtype=torch.float64).reshape(B, -1) + 1000.0 * r + step
+        assert torch.equal(both[r * B:(r + 1) * B], exp), (rank, r, step)
 if rank == 0:
     np.save(sys.argv[2], allrec)
     assert tmax == float(world), tmax
