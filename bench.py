@@ -450,7 +450,9 @@ def main():
     import multiprocessing as mp
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4
     nproc = max(1, min(16 // max(1, min(world, 8)), ncpu, nu))
-    if nproc > 1:
+    # under rocprofv3 the preloaded tool library has initialised the GPU before this program starts: no forked helpers then
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ)
+    if nproc > 1 and not profiled:
         with mp.get_context("fork").Pool(nproc) as pool:
             scenes = make_cases(nu, 1000 + 100 * rank, W, H, pool)
     else:

@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libsdslam_hip.so")
+OUT = os.environ.get("SD_OUT") or os.path.join(HERE, "libsdslam_hip.so")   # SD_OUT: instrumented builds beside the product (tools/)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 

@@ -25,7 +25,8 @@ class SdError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libsdslam_hip.so")
+    # SD_LIB: an instrumented build of the same library (profiling tools only; e.g. -DSD_PNP_PROF stage timers)
+    return os.environ.get("SD_LIB") or os.path.join(_HERE, "libsdslam_hip.so")
 
 
 _lib = None

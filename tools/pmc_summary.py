@@ -16,6 +16,10 @@ import sys
 from collections import defaultdict
 
 
+# FETCH_SIZE calibration factor per kernel (default 2: wide / coalesced streams)
+CAL = {"k_fast_cells": 1.0}
+
+
 def short(name):
     n = name.split("(")[0]
     return n.replace("sd::", "")
@@ -44,7 +48,15 @@ def main():
             e[c + "_per_launch"] = out[k][c] / max(cnt[k][c], 1)
             e[c + "_samples"] = cnt[k][c]
         if "FETCH_SIZE_per_launch" in e:
-            e["FETCH_bytes_corrected_per_launch"] = e["FETCH_SIZE_per_launch"] * 1024 * 2
+            # rocprofv3's FETCH_SIZE tallies every EA read request at 64 B (its 128-B term, TCC_BUBBLE, stays 0 on gfx950):
+            # streams of full 128-B requests read exactly half (x2: MI355X_MICROARCH.md, re-measured for dwordx4 AND plain dword
+            # coalesced loads: profiles/r02_fetch_calibration.json); short unaligned row segments (the FAST tile staging: 132-B
+            # rows at a 768-B pitch) go out as 64-B requests and read the true byte count (x1).  Both are reported; the
+            # per-kernel choice is CAL below (calibrated with tools/valu_microbench --stream).
+            raw = e["FETCH_SIZE_per_launch"] * 1024
+            e["FETCH_bytes_raw_per_launch"] = raw
+            e["FETCH_bytes_x2_per_launch"] = raw * 2
+            e["FETCH_bytes_corrected_per_launch"] = raw * CAL.get(k.replace("void ", "").split("<")[0], 2.0)
         if "WRITE_SIZE_per_launch" in e:
             e["WRITE_bytes_per_launch"] = e["WRITE_SIZE_per_launch"] * 1024
         res[k] = e

@@ -46,8 +46,8 @@ for _ in range(3):
     trk.align(B, 0)
 L.sd_debug_align_prof(aout, 1)
 av = np.array(list(aout), np.float64) / (B * 3)
-an = ["gather+init", "precompute patches", "pose (tid0) + barrier", "residuals+J", "reduce + barrier", "serial: H + float chi2 sum",
-      "serial: LDLT + exp + update", "barrier"]
+an = ["gather+init", "precompute patches (per level)", "-", "residuals (project, loads, 16 px)", "H/Jres wave reductions + barrier",
+      "float chi2 chain (wave 0) || LDLT+exp (wave 1) + barrier", "decisions + next pose (tid 0)", "barrier"]
 print("k_align phases (cycles of thread 0 per frame)")
 for i, nme in enumerate(an):
     print(f"  {nme:30s} {av[i]:12.0f}")

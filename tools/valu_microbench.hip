@@ -1,0 +1,274 @@
+// tools/valu_microbench.hip -- what the vector ALUs of an MI355X really sustain for the instructions the FAST / pyramid /
+// matcher kernels are made of, at 1, 2, 4 and 8 resident waves per SIMD (VERDICT r1 "next" 3.i), plus three streaming-read
+// kernels of known byte counts for calibrating rocprofv3's FETCH_SIZE on narrow loads (3.ii).
+//
+//   hipcc -O3 --offload-arch=gfx950 tools/valu_microbench.hip -o tools/build/valu_microbench
+//   tools/build/valu_microbench            # prints a JSON object (cycles per wave64 instruction per SIMD)
+//   rocprofv3 --pmc FETCH_SIZE ... -- tools/build/valu_microbench --stream   # only the three stream kernels
+//
+// Method: every wave runs ITERS x 32 instructions of one kind (8 independent dependency chains, so latency never limits a
+// single wave), stamped with s_memtime (tick = shader cycle, MI355X_MICROARCH.md).  W waves per SIMD: 256 workgroups of
+// 4 W waves (W <= 4; W = 8: 512 workgroups of 16 waves, 64 KB of LDS each so that two fit a CU and three do not); every wave
+// also records where it ran (HW_ID / XCC_ID), and the host reports how many waves really shared a SIMD.
+// cycles per instruction per SIMD = median over waves of (elapsed / instructions) / (waves on that SIMD).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+enum { OP_MAX3 = 0, OP_MIN3, OP_PERM, OP_MUL24, OP_MAD24, OP_CMP_SOR, OP_PKMAX16, OP_PKMIN16, OP_ADD, OP_BCNT, OP_ALIGNBYTE, OP_ANDOR, OP_LSHLADD,
+       OP_CNDMASK, OP_SUBREV, OP_DS_READ_U8, OP_DS_READ_B32, OP_COUNT };
+static const char* kNames[OP_COUNT] = {"v_max3_i32", "v_min3_i32", "v_perm_b32", "v_mul_i32_i24", "v_mad_i32_i24", "v_cmp_lt_i32+s_or_b64", "v_pk_max_u16",
+                                       "v_pk_min_u16", "v_add_u32", "v_bcnt_u32_b32", "v_alignbyte_b32", "v_and_or_b32", "v_lshl_add_u32", "v_cndmask_b32",
+                                       "v_subrev_u32", "ds_read_u8", "ds_read_b32"};
+
+#define REP8(S)  S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
+
+template <int OP>
+__global__ __launch_bounds__(1024) void k_issue(unsigned long long* __restrict__ out, int iters, unsigned seed) {
+  extern __shared__ unsigned char lds[];
+  unsigned a[8];
+  const unsigned t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; i++) a[i] = seed * (i + 3) + t * 2654435761u;
+  unsigned b = seed ^ 0x9e3779b9u, c = t | 0x01020304u;
+  if (OP == OP_DS_READ_U8 || OP == OP_DS_READ_B32) {
+    for (int i = t; i < 4096; i += blockDim.x) ((unsigned*)lds)[i] = i * 7u;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = (t * 4 + i * 1024) & 16380;
+  }
+  unsigned long long sacc = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (OP == OP_MAX3) {
+#define S(i) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        REP8(S)
+#undef S
+      } else if (OP == OP_MIN3) {
+#define S(i) asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        REP8(S)
+#undef S
+      } else if (OP == OP_PERM) {
+#define S(i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        REP8(S)
+#undef S
+      } else if (OP == OP_MUL24) {
+#define S(i) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_MAD24) {
+#define S(i) asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        REP8(S)
+#undef S
+      } else if (OP == OP_CMP_SOR) {
+        // the FAST compass test's shape: a compare into an SGPR pair, combined on the scalar unit
+#define S(i) asm volatile("v_cmp_lt_i32 vcc, %1, %2\n s_or_b64 %0, %0, vcc" : "+s"(sacc) : "v"(a[i]), "v"(b) : "vcc", "scc");
+        REP8(S)
+#undef S
+      } else if (OP == OP_PKMAX16) {
+#define S(i) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_PKMIN16) {
+#define S(i) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_ADD) {
+#define S(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_BCNT) {
+#define S(i) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_ALIGNBYTE) {
+#define S(i) asm volatile("v_alignbyte_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        REP8(S)
+#undef S
+      } else if (OP == OP_ANDOR) {
+#define S(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        REP8(S)
+#undef S
+      } else if (OP == OP_LSHLADD) {
+#define S(i) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_CNDMASK) {
+#define S(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+        REP8(S)
+#undef S
+      } else if (OP == OP_SUBREV) {
+#define S(i) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_DS_READ_U8) {
+        unsigned v[8];
+#define S(i) asm volatile("ds_read_u8 %0, %1" : "=v"(v[i]) : "v"(a[i]));
+        REP8(S)
+#undef S
+        asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+        for (int i = 0; i < 8; i++) c ^= v[i];
+      } else {
+        unsigned v[8];
+#define S(i) asm volatile("ds_read_b32 %0, %1" : "=v"(v[i]) : "v"(a[i]));
+        REP8(S)
+#undef S
+        asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+        for (int i = 0; i < 8; i++) c ^= v[i];
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned s = c ^ (unsigned)sacc;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s ^= a[i];
+  if ((t & 63) == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (t >> 6);
+    out[2 * w] = (t1 - t0) + (s == 0x12345u);
+    out[2 * w + 1] = ((unsigned long long)(xcc & 0xf) << 32) | (hw & 0xfff0u);   // simd [5:4], pipe [7:6], cu [11:8], sh [12], se [15:13]
+  }
+}
+
+// ---- streaming reads of known size (FETCH_SIZE calibration): every byte of `n` bytes is read exactly once
+__global__ void k_stream_dwordx4(const uint4* __restrict__ p, size_t n16, unsigned* __restrict__ sink) {
+  unsigned acc = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 v = p[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x1234567u) *sink = acc;
+}
+__global__ void k_stream_dword(const unsigned* __restrict__ p, size_t n4, unsigned* __restrict__ sink) {
+  unsigned acc = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) acc ^= p[i];
+  if (acc == 0x1234567u) *sink = acc;
+}
+__global__ void k_stream_byte(const unsigned char* __restrict__ p, size_t n, unsigned* __restrict__ sink) {
+  unsigned acc = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc ^= p[i];
+  if (acc == 0x1234567u) *sink = acc;
+}
+// the FAST tile-staging shape: rows of `roww` aligned dwords out of a pitch-`pitch` image, one 2-D tile per workgroup, tiles
+// overlap by `halo` rows/columns (re-reads that L2 should absorb)
+__global__ void k_stream_tiles(const unsigned* __restrict__ p, int pitch_w, int tile_w, int tile_h, int step_w, int step_h, int ntx, unsigned* __restrict__ sink) {
+  const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+  const unsigned* g = p + (size_t)blockIdx.y * pitch_w * 4096 + (size_t)ty * step_h * pitch_w + tx * step_w;
+  unsigned acc = 0;
+  for (int i = threadIdx.x; i < tile_w * tile_h; i += blockDim.x) acc ^= g[(size_t)(i / tile_w) * pitch_w + (i % tile_w)];
+  if (acc == 0x1234567u) *sink = acc;
+}
+
+template <int OP>
+static double run_issue(int W, int iters, unsigned long long* d_out, std::vector<unsigned long long>& h, double* mean_share, double* wall_cyc) {
+  const int wpb = W <= 4 ? 4 * W : 16, nblk = W <= 4 ? 256 : 512;
+  const size_t lds = 64 * 1024;
+  fprintf(stderr, "op %d W %d ...", OP, W);
+  fflush(stderr);
+  hipLaunchKernelGGL(k_issue<OP>, dim3(nblk), dim3(64 * wpb), lds, 0, d_out, 64, 1u);   // warm-up (clocks, code)
+  CK(hipDeviceSynchronize());
+  static hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (!e0) { CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); }
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(k_issue<OP>, dim3(nblk), dim3(64 * wpb), lds, 0, d_out, iters, 2u);
+  CK(hipEventRecord(e1));
+  CK(hipGetLastError());
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  // the same figure from the host clock: kernel time x 2.4 GHz / (instructions per wave x waves per SIMD)
+  *wall_cyc = (double)ms * 1e-3 * 2.4e9 / ((double)iters * 32.0 * W);
+  const size_t nw = (size_t)nblk * wpb;
+  h.resize(nw * 2);
+  CK(hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> where(nw);
+  for (size_t i = 0; i < nw; i++) where[i] = h[2 * i + 1];
+  std::vector<unsigned long long> sorted = where;
+  std::sort(sorted.begin(), sorted.end());
+  std::vector<double> c;
+  double share = 0;
+  for (size_t i = 0; i < nw; i++) {
+    const auto r = std::equal_range(sorted.begin(), sorted.end(), where[i]);
+    const double on_simd = (double)(r.second - r.first);   // waves of this launch that ran on the same SIMD
+    share += on_simd;
+    c.push_back((double)h[2 * i] / ((double)iters * 32.0) / on_simd);
+  }
+  std::sort(c.begin(), c.end());
+  *mean_share = share / nw;
+  fprintf(stderr, " done\n");
+  return c[c.size() / 2];
+}
+
+int main(int argc, char** argv) {
+  const bool stream_only = argc > 1 && !strcmp(argv[1], "--stream");
+  CK(hipSetDevice(0));
+  unsigned long long* d_out;
+  CK(hipMalloc(&d_out, 512 * 16 * 2 * 8));
+  std::vector<unsigned long long> h;
+  if (!stream_only) {
+    printf("{\"unit\": \"shader cycles per wave64 instruction per SIMD (median over all waves; W waves resident per SIMD)\",\n \"ops\": {\n");
+    const int Ws[4] = {1, 2, 4, 8};
+    for (int op = 0; op < OP_COUNT; op++) {
+      printf("  \"%s\": {", kNames[op]);
+      for (int wi = 0; wi < 4; wi++) {
+        const int W = Ws[wi], iters = 16384;
+        double r = 0, share = 0, wall = 0;
+        switch (op) {
+#define C(O) case O: r = run_issue<O>(W, iters, d_out, h, &share, &wall); break;
+          C(OP_MAX3) C(OP_MIN3) C(OP_PERM) C(OP_MUL24) C(OP_MAD24) C(OP_CMP_SOR) C(OP_PKMAX16) C(OP_PKMIN16) C(OP_ADD) C(OP_BCNT) C(OP_ALIGNBYTE)
+          C(OP_ANDOR) C(OP_LSHLADD) C(OP_CNDMASK) C(OP_SUBREV) C(OP_DS_READ_U8) C(OP_DS_READ_B32)
+#undef C
+        }
+        printf("\"W%d\": %.3f, \"W%d_waves_sharing_simd\": %.2f, \"W%d_from_event_time_at_2.4GHz\": %.3f%s", W, r, W, share, W, wall, wi < 3 ? ", " : "");
+        fflush(stdout);
+      }
+      printf("}%s\n", op + 1 < OP_COUNT ? "," : "");
+    }
+    printf(" },\n");
+  } else {
+    printf("{\n");
+  }
+  // ---- streaming reads: 1 GiB each (past the 256 MiB Infinity Cache), every byte once
+  const size_t n = (size_t)1 << 30;
+  unsigned char* buf;
+  unsigned* sink;
+  CK(hipMalloc(&buf, n));
+  CK(hipMalloc(&sink, 4));
+  CK(hipMemset(buf, 1, n));
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float ms[4];
+  for (int k = 0; k < 4; k++) {
+    CK(hipEventRecord(e0));
+    if (k == 0) hipLaunchKernelGGL(k_stream_dwordx4, dim3(256 * 32), dim3(256), 0, 0, (const uint4*)buf, n / 16, sink);
+    if (k == 1) hipLaunchKernelGGL(k_stream_dword, dim3(256 * 32), dim3(256), 0, 0, (const unsigned*)buf, n / 4, sink);
+    if (k == 2) hipLaunchKernelGGL(k_stream_byte, dim3(256 * 32), dim3(256), 0, 0, buf, n / 4, sink);   // 256 MiB of bytes
+    if (k == 3)   // 1024 "frames" of 4096 rows x 1024 B pitch... : tiles of 33 x 80 dwords stepping 30 x 74 (FAST level-0 cell + halo)
+      hipLaunchKernelGGL(k_stream_tiles, dim3(5 * 6, 1024 / 16), dim3(256), 0, 0, (const unsigned*)buf, 192, 33, 80, 30, 74, 5, sink);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms[k], e0, e1));
+  }
+  const double tiles_unique = 64.0 * (4 * 30 + 33) * (5 * 74 + 80) * 4, tiles_issued = 64.0 * 30 * 33 * 80 * 4;
+  printf(" \"stream\": {\"k_stream_dwordx4\": {\"bytes\": %zu, \"ms\": %.3f, \"GBps\": %.1f},\n"
+         "            \"k_stream_dword\": {\"bytes\": %zu, \"ms\": %.3f, \"GBps\": %.1f},\n"
+         "            \"k_stream_byte\": {\"bytes\": %zu, \"ms\": %.3f, \"GBps\": %.1f},\n"
+         "            \"k_stream_tiles\": {\"bytes_unique\": %.0f, \"bytes_issued\": %.0f, \"ms\": %.3f}}\n}\n",
+         n, ms[0], n / ms[0] / 1e6, n, ms[1], n / ms[1] / 1e6, n / 4, ms[2], n / 4 / ms[2] / 1e6, tiles_unique, tiles_issued, ms[3]);
+  return 0;
+}
