@@ -65,6 +65,17 @@ __device__ __forceinline__ void m4_mul_lds(const ldsd* a, const ldsd* b, ldsd* r
   }
 }
 
+// the same product by 16 lanes (lane l < 16 computes entry l): every entry is the same four multiply-adds in the same order
+__device__ __forceinline__ void m4_mul_lds16(const ldsd* a, const ldsd* b, ldsd* r, int l) {
+  if (l < 16) {
+    const int i = l >> 2, j = l & 3;
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s += a[i * 4 + k] * b[k * 4 + j];
+    r[l] = s;
+  }
+}
+
 // Eigen 3.3 LDLT<Matrix6d>::solve (pivoting on the largest |diagonal|, pseudo-inverse of D); A row-major 6 x 6, everything
 // in LDS (tmp: 12 doubles, tr: 6 ints), single lane
 #define A_(r, c) A[(r) * 6 + (c)]
@@ -73,68 +84,68 @@ __device__ __forceinline__ void ldlt_solve6(ldsd* A, const ldsd* b, ldsd* x, lds
   ldsd* temp = tmp;
   ldsd* d = tmp + 6;
   bool done = false;
-  NOUNROLL for (int k = 0; k < n && !done; ++k) {
+  for (int k = 0; k < n && !done; ++k) {
     int big = k;
     double best = fabs(A_(k, k));
-    NOUNROLL for (int i = k + 1; i < n; i++) {
+    for (int i = k + 1; i < n; i++) {
       const double v = fabs(A_(i, i));
       if (v > best) { best = v; big = i; }
     }
     tr[k] = big;
     if (k != big) {
       int s = n - big - 1;
-      NOUNROLL for (int j = 0; j < k; j++) { double t = A_(k, j); A_(k, j) = A_(big, j); A_(big, j) = t; }
-      NOUNROLL for (int i = 0; i < s; i++) { double t = A_(big + 1 + i, k); A_(big + 1 + i, k) = A_(big + 1 + i, big); A_(big + 1 + i, big) = t; }
+      for (int j = 0; j < k; j++) { double t = A_(k, j); A_(k, j) = A_(big, j); A_(big, j) = t; }
+      for (int i = 0; i < s; i++) { double t = A_(big + 1 + i, k); A_(big + 1 + i, k) = A_(big + 1 + i, big); A_(big + 1 + i, big) = t; }
       { double t = A_(k, k); A_(k, k) = A_(big, big); A_(big, big) = t; }
-      NOUNROLL for (int i = k + 1; i < big; ++i) { double t = A_(i, k); A_(i, k) = A_(big, i); A_(big, i) = t; }
+      for (int i = k + 1; i < big; ++i) { double t = A_(i, k); A_(i, k) = A_(big, i); A_(big, i) = t; }
     }
     int rs = n - k - 1;
     if (k > 0) {
-      NOUNROLL for (int j = 0; j < k; j++) temp[j] = A_(j, j) * A_(k, j);
+      for (int j = 0; j < k; j++) temp[j] = A_(j, j) * A_(k, j);
       double s = 0;
-      NOUNROLL for (int j = 0; j < k; j++) s += A_(k, j) * temp[j];
+      for (int j = 0; j < k; j++) s += A_(k, j) * temp[j];
       A_(k, k) -= s;
-      NOUNROLL for (int i = 0; i < rs; i++) {
+      for (int i = 0; i < rs; i++) {
         double t = 0;
-        NOUNROLL for (int j = 0; j < k; j++) t += A_(k + 1 + i, j) * temp[j];
+        for (int j = 0; j < k; j++) t += A_(k + 1 + i, j) * temp[j];
         A_(k + 1 + i, k) -= t;
       }
     }
     double akk = A_(k, k);
     bool valid = fabs(akk) > 0.0;
     if (k == 0 && !valid) {
-      NOUNROLL for (int j = 0; j < n; j++) tr[j] = j;
+      for (int j = 0; j < n; j++) tr[j] = j;
       done = true;
     } else if (rs > 0 && valid) {
-      NOUNROLL for (int i = 0; i < rs; i++) A_(k + 1 + i, k) /= akk;
+      for (int i = 0; i < rs; i++) A_(k + 1 + i, k) /= akk;
     }
   }
-  NOUNROLL for (int i = 0; i < n; i++) d[i] = b[i];
-  NOUNROLL for (int k = 0; k < n; k++) {
+  for (int i = 0; i < n; i++) d[i] = b[i];
+  for (int k = 0; k < n; k++) {
     const int t_ = tr[k];
     if (t_ != k) { double t = d[k]; d[k] = d[t_]; d[t_] = t; }
   }
-  NOUNROLL for (int i = 0; i < n; i++) {
+  for (int i = 0; i < n; i++) {
     double di = d[i];
-    NOUNROLL for (int j = 0; j < i; j++) di -= A_(i, j) * d[j];
+    for (int j = 0; j < i; j++) di -= A_(i, j) * d[j];
     d[i] = di;
   }
   const double tol = 2.2250738585072014e-308;
-  NOUNROLL for (int i = 0; i < n; i++) {
+  for (int i = 0; i < n; i++) {
     const double aii = A_(i, i);
     if (fabs(aii) > tol) d[i] /= aii;
     else d[i] = 0;
   }
-  NOUNROLL for (int i = n - 1; i >= 0; i--) {
+  for (int i = n - 1; i >= 0; i--) {
     double di = d[i];
-    NOUNROLL for (int j = i + 1; j < n; j++) di -= A_(j, i) * d[j];
+    for (int j = i + 1; j < n; j++) di -= A_(j, i) * d[j];
     d[i] = di;
   }
-  NOUNROLL for (int k = n - 1; k >= 0; k--) {
+  for (int k = n - 1; k >= 0; k--) {
     const int t_ = tr[k];
     if (t_ != k) { double t = d[k]; d[k] = d[t_]; d[t_] = t; }
   }
-  NOUNROLL for (int i = 0; i < n; i++) x[i] = d[i];
+  for (int i = 0; i < n; i++) x[i] = d[i];
 }
 #undef A_
 
@@ -557,41 +568,46 @@ __global__ __launch_bounds__(AL_PT_THREADS, MINW) void k_align(const OrbPlan* __
         if (lane == 0) s_chi[0] = chi2f;   // the terms are consumed
       }
       // ------------------------------------------------ wave 1, lane 0 (beside the chain): H_.ldlt().solve(Jres_), Exp(-x)
-      if (tid == 64) {
-        if (it == 0) {   // the level's H over the waves
-          NOUNROLL for (int q = 0; q < 21; q++) {
-            double v = s_redH[0][q];
-            NOUNROLL for (int w = 1; w < AL_PT_WAVES; w++) v += s_redH[w][q];
-            s_Hlvl[q] = v;
+      if (wave == 1) {
+        // wave 1 beside the chain: H and Jres over the waves (one lane per entry), the solve and Exp on lane 0, the two 4 x 4
+        // products on 16 lanes (single wave: LDS operations complete in order, no barrier needed between the steps)
+        if (lane < 21) {
+          if (it == 0) {   // the level's H over the waves
+            double v = s_redH[0][lane];
+#pragma unroll
+            for (int w = 1; w < AL_PT_WAVES; w++) v += s_redH[w][lane];
+            s_Hlvl[lane] = v;
           }
-        }
-        int q = 0;
-        NOUNROLL for (int a = 0; a < 6; a++) {
-          NOUNROLL for (int bb = a; bb < 6; bb++) {
-            double v = s_Hlvl[q];
-            NOUNROLL for (int w = 0; w < AL_PT_WAVES; w++)
-              if (s_delta[w]) v -= s_red[w][q];
-            s_H[a * 6 + bb] = v;
-            s_H[bb * 6 + a] = v;
-            q++;
-          }
-        }
-        NOUNROLL for (int a = 0; a < 6; a++) {
+          double v = s_Hlvl[lane];
+#pragma unroll
+          for (int w = 0; w < AL_PT_WAVES; w++)
+            if (s_delta[w]) v -= s_red[w][lane];
+          // entry q = lane of the upper triangle, row-major: (a, bb)
+          int a = 0, q = lane;
+          while (q >= 6 - a) { q -= 6 - a; a++; }
+          const int bb = a + q;
+          s_H[a * 6 + bb] = v;
+          s_H[bb * 6 + a] = v;
+        } else if (lane < 27) {
+          const int a = lane - 21;
           double v = s_red[0][21 + a];
-          NOUNROLL for (int w = 1; w < AL_PT_WAVES; w++) v += s_red[w][21 + a];
+#pragma unroll
+          for (int w = 1; w < AL_PT_WAVES; w++) v += s_red[w][21 + a];
           s_b[a] = v;
         }
-        ldlt_solve6(LDSD(s_H), LDSD(s_b), LDSD(s_x), LDSD(s_tmp), (ldsi*)s_tr);
-        double mx = -1;
-        NOUNROLL for (int i = 0; i < 6; i++) {
-          const double xi = s_x[i];
-          s_nx[i] = -xi;
-          if (fabs(xi) > mx) mx = fabs(xi);
+        if (lane == 0) {
+          ldlt_solve6(LDSD(s_H), LDSD(s_b), LDSD(s_x), LDSD(s_tmp), (ldsi*)s_tr);
+          double mx = -1;
+          NOUNROLL for (int i = 0; i < 6; i++) {
+            const double xi = s_x[i];
+            s_nx[i] = -xi;
+            if (fabs(xi) > mx) mx = fabs(xi);
+          }
+          se3_exp(LDSD(s_nx), LDSD(s_E), LDSD(s_tmp));
+          s_mx = mx;
         }
-        se3_exp(LDSD(s_nx), LDSD(s_E), LDSD(s_tmp));
-        m4_mul_lds(LDSD(s_se3), LDSD(s_E), LDSD(s_cand));   // se3 * Exp(-x): used only if the step is accepted
-        m4_mul_lds(LDSD(s_cand), LDSD(s_last), LDSD(s_posec));   // ... and the trial pose that goes with it
-        s_mx = mx;
+        m4_mul_lds16(LDSD(s_se3), LDSD(s_E), LDSD(s_cand), lane);     // se3 * Exp(-x): used only if the step is accepted
+        m4_mul_lds16(LDSD(s_cand), LDSD(s_last), LDSD(s_posec), lane);   // ... and the trial pose that goes with it
       }
       __syncthreads();
       APROF(5);

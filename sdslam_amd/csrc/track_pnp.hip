@@ -586,6 +586,7 @@ __device__ void epnp_L_rho(Ptr ut, const double cws[4][3], Ptr L, double rho[6],
 // only on L and rho, never on each other, so they run on three lanes side by side.
 template <typename Ptr>
 __device__ __noinline__ void epnp_betas(int variant, Ptr L, const double* rho, double betas[4]) {
+  PROF_DECL;
   if (variant == 1) {
     double l[24], b4[4];
     for (int i = 0; i < 6; i++) {
@@ -640,6 +641,7 @@ __device__ __noinline__ void epnp_betas(int variant, Ptr L, const double* rho, d
     betas[2] = b5[3] / betas[0];
     betas[3] = 0.0;
   }
+  PROF(5);
   for (int k = 0; k < 5; k++) {
     double a[24], b[6], x[4] = {0, 0, 0, 0};
     for (int i = 0; i < 6; i++) {
@@ -657,6 +659,7 @@ __device__ __noinline__ void epnp_betas(int variant, Ptr L, const double* rho, d
     qr_solve64(a, b, x);
     for (int i = 0; i < 4; i++) betas[i] += x[i];
   }
+  PROF(6);
 }
 
 // compute_ccs
@@ -776,7 +779,7 @@ __device__ __noinline__ double epnp_minimal(bool active, int variant, const doub
   if (active) {
     double betas[4], ccs[4][3], pcs[12];
     epnp_betas(variant, L, rho, betas);
-    PROF(6);
+    PROF(9);   // (timed inside: slots 5 / 6)
     epnp_ccs(ut, betas, ccs);
     for (int i = 0; i < n; i++) {
       const double* a = alphas + 4 * i;
