@@ -421,6 +421,155 @@ __device__ __noinline__ void solve_svd6(const double* A, const double* b, double
   for (int i = 0; i < N; i++) x[i] = xr[i];
 }
 
+// The three find_betas variants solve 6 x 4, 6 x 3 and 6 x 5 systems on three lanes of ONE wave: as three template
+// instantiations they are three instruction streams that the wave executes one after the other (each with one lane active).
+// This is the same one-sided Jacobi SVD + back-substitution with the column count N as a per-lane RUN-TIME value on a
+// 5-row register layout: every loop is unrolled over the 5 rows and row i takes part iff i < N, so the lanes share one
+// instruction stream and run side by side.  The operations a lane performs on its real rows, and their order, are exactly
+// those of jacobi_svd_small<6, N> / solve_svd6<N> (the pairs (i, j), i < j < N, of the 5-row cyclic order are the N-row
+// cyclic order; a sweep over a converged matrix rotates nothing), so the results are bit-identical.
+__device__ __noinline__ void solve_svd6_n(int N, const double* A /* 6 x N row-major */, const double* b, double* x) {
+  constexpr int M = 6, NM = 5;
+  const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+  double At[NM][M], Vt[NM][NM], W[NM];
+#pragma unroll
+  for (int i = 0; i < NM; i++) {
+#pragma unroll
+    for (int j = 0; j < M; j++) At[i][j] = i < N ? A[j * N + i] : 0.0;
+    double sd = 0;
+#pragma unroll
+    for (int k = 0; k < M; k++) sd += At[i][k] * At[i][k];
+    W[i] = sd;
+#pragma unroll
+    for (int k = 0; k < NM; k++) Vt[i][k] = k == i ? 1 : 0;
+  }
+  bool live = true;   // this lane's matrix still rotates
+  for (int iter = 0; iter < 30; iter++) {   // max_iter = max(m, 30)
+    bool changed = false;
+#pragma unroll
+    for (int i = 0; i < NM - 1; i++) {
+#pragma unroll
+      for (int j = i + 1; j < NM; j++) {
+        if (live && j < N) {
+          double p = 0;
+#pragma unroll
+          for (int k = 0; k < M; k++) p += At[i][k] * At[j][k];
+          if (!(fabs(p) <= eps * sqrt(W[i] * W[j]))) {
+            p *= 2;
+            double c, sn;
+            const double beta = W[i] - W[j], gamma = sdsc::hypot_glibc(p, beta);
+            if (beta < 0) {
+              const double delta = (gamma - beta) * 0.5;
+              sn = sqrt(delta / gamma);
+              c = p / (gamma * sn * 2);
+            } else {
+              c = sqrt((gamma + beta) / (gamma * 2));
+              sn = p / (gamma * c * 2);
+            }
+            double na = 0, nb = 0;
+#pragma unroll
+            for (int k = 0; k < M; k++) {
+              const double t0 = c * At[i][k] + sn * At[j][k];
+              const double t1 = -sn * At[i][k] + c * At[j][k];
+              At[i][k] = t0;
+              At[j][k] = t1;
+              na += t0 * t0;
+              nb += t1 * t1;
+            }
+            W[i] = na;
+            W[j] = nb;
+            changed = true;
+#pragma unroll
+            for (int k = 0; k < NM; k++) {
+              const double t0 = c * Vt[i][k] + sn * Vt[j][k];
+              const double t1 = -sn * Vt[i][k] + c * Vt[j][k];
+              Vt[i][k] = t0;
+              Vt[j][k] = t1;
+            }
+          }
+        }
+      }
+    }
+    live = live && changed;   // the sequential loop's `if (!changed) break`
+    if (!__any(live)) break;
+  }
+#pragma unroll
+  for (int i = 0; i < NM; i++) {
+    double sd = 0;
+#pragma unroll
+    for (int k = 0; k < M; k++) sd += At[i][k] * At[i][k];
+    W[i] = sqrt(sd);
+  }
+#pragma unroll
+  for (int i = 0; i < NM - 1; i++) {   // selection sort, descending, over the lane's N rows
+    int j = i;
+    double wj = W[i];
+#pragma unroll
+    for (int k = i + 1; k < NM; k++)
+      if (k < N && wj < W[k]) {
+        j = k;
+        wj = W[k];
+      }
+#pragma unroll
+    for (int jj = i + 1; jj < NM; jj++)
+      if (jj == j) {
+        const double tw = W[i]; W[i] = W[jj]; W[jj] = tw;
+#pragma unroll
+        for (int k = 0; k < M; k++) { const double t = At[i][k]; At[i][k] = At[jj][k]; At[jj][k] = t; }
+#pragma unroll
+        for (int k = 0; k < NM; k++) { const double t = Vt[i][k]; Vt[i][k] = Vt[jj][k]; Vt[jj][k] = t; }
+      }
+  }
+  double w[NM];
+#pragma unroll
+  for (int i = 0; i < NM; i++) w[i] = W[i];
+  unsigned long long rng = 0x12345678ull;
+#pragma unroll
+  for (int i = 0; i < NM; i++) {
+    if (i < N) {
+      double sd = W[i];
+      if (sd <= minval) {   // vanished singular value: build an orthogonal row (generic path on a copy of the N rows)
+        double tmp[NM * M];
+        for (int r = 0; r < NM; r++)
+          for (int k = 0; k < M; k++) tmp[r * M + k] = At[r][k];
+        sd = jacobi_fill_row(tmp, M, M, i, &rng, sd);
+#pragma unroll
+        for (int k = 0; k < M; k++) At[i][k] = tmp[i * M + k];
+      }
+      const double sc = sd > minval ? 1 / sd : 0.;
+#pragma unroll
+      for (int k = 0; k < M; k++) At[i][k] *= sc;
+    }
+  }
+  // cvSolve's back substitution
+  double xr[NM];
+#pragma unroll
+  for (int i = 0; i < NM; i++) xr[i] = 0;
+  double threshold = 0;
+#pragma unroll
+  for (int i = 0; i < NM; i++)
+    if (i < N) threshold += w[i];
+  threshold *= DBL_EPSILON * 2;
+#pragma unroll
+  for (int i = 0; i < NM; i++) {
+    if (i < N) {
+      double wi = w[i];
+      if (!(fabs(wi) <= threshold)) {
+        wi = 1 / wi;
+        double sacc = 0;
+#pragma unroll
+        for (int j = 0; j < M; j++) sacc += At[i][j] * b[j];
+        sacc *= wi;
+#pragma unroll
+        for (int j = 0; j < NM; j++) xr[j] = xr[j] + sacc * Vt[i][j];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NM; i++)
+    if (i < N) x[i] = xr[i];
+}
+
 __device__ void invert_svd3(const double* A, double* Ainv) {
   double w[3], ut[9], vt[9];
   svd3(A, w, ut, vt);
@@ -587,58 +736,57 @@ __device__ void epnp_L_rho(Ptr ut, const double cws[4][3], Ptr L, double rho[6],
 template <typename Ptr>
 __device__ __noinline__ void epnp_betas(int variant, Ptr L, const double* rho, double betas[4]) {
   PROF_DECL;
-  if (variant == 1) {
-    double l[24], b4[4];
-    for (int i = 0; i < 6; i++) {
+  // find_betas_approx_{1,2,3} (src/PnPsolver.cc:700-780): the variant picks its columns of L, one shared solver
+  const int N = variant == 1 ? 4 : (variant == 2 ? 3 : 5);
+  double l[30], bs[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 6; i++) {
+    if (variant == 1) {
       l[4 * i] = L[10 * i];
       l[4 * i + 1] = L[10 * i + 1];
       l[4 * i + 2] = L[10 * i + 3];
       l[4 * i + 3] = L[10 * i + 6];
-    }
-    solve_svd6<4>(l, rho, b4);
-    if (b4[0] < 0) {
-      betas[0] = sqrt(-b4[0]);
-      betas[1] = -b4[1] / betas[0];
-      betas[2] = -b4[2] / betas[0];
-      betas[3] = -b4[3] / betas[0];
-    } else {
-      betas[0] = sqrt(b4[0]);
-      betas[1] = b4[1] / betas[0];
-      betas[2] = b4[2] / betas[0];
-      betas[3] = b4[3] / betas[0];
-    }
-  } else if (variant == 2) {
-    double l[18], b3[3];
-    for (int i = 0; i < 6; i++) {
+    } else if (variant == 2) {
       l[3 * i] = L[10 * i];
       l[3 * i + 1] = L[10 * i + 1];
       l[3 * i + 2] = L[10 * i + 2];
-    }
-    solve_svd6<3>(l, rho, b3);
-    if (b3[0] < 0) {
-      betas[0] = sqrt(-b3[0]);
-      betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0;
     } else {
-      betas[0] = sqrt(b3[0]);
-      betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0;
+      for (int j = 0; j < 5; j++) l[5 * i + j] = L[10 * i + j];
     }
-    if (b3[1] < 0) betas[0] = -betas[0];
+  }
+  solve_svd6_n(N, l, rho, bs);
+  if (variant == 1) {
+    if (bs[0] < 0) {
+      betas[0] = sqrt(-bs[0]);
+      betas[1] = -bs[1] / betas[0];
+      betas[2] = -bs[2] / betas[0];
+      betas[3] = -bs[3] / betas[0];
+    } else {
+      betas[0] = sqrt(bs[0]);
+      betas[1] = bs[1] / betas[0];
+      betas[2] = bs[2] / betas[0];
+      betas[3] = bs[3] / betas[0];
+    }
+  } else if (variant == 2) {
+    if (bs[0] < 0) {
+      betas[0] = sqrt(-bs[0]);
+      betas[1] = (bs[2] < 0) ? sqrt(-bs[2]) : 0.0;
+    } else {
+      betas[0] = sqrt(bs[0]);
+      betas[1] = (bs[2] > 0) ? sqrt(bs[2]) : 0.0;
+    }
+    if (bs[1] < 0) betas[0] = -betas[0];
     betas[2] = 0.0;
     betas[3] = 0.0;
   } else {
-    double l[30], b5[5];
-    for (int i = 0; i < 6; i++)
-      for (int j = 0; j < 5; j++) l[5 * i + j] = L[10 * i + j];
-    solve_svd6<5>(l, rho, b5);
-    if (b5[0] < 0) {
-      betas[0] = sqrt(-b5[0]);
-      betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0;
+    if (bs[0] < 0) {
+      betas[0] = sqrt(-bs[0]);
+      betas[1] = (bs[2] < 0) ? sqrt(-bs[2]) : 0.0;
     } else {
-      betas[0] = sqrt(b5[0]);
-      betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0;
+      betas[0] = sqrt(bs[0]);
+      betas[1] = (bs[2] > 0) ? sqrt(bs[2]) : 0.0;
     }
-    if (b5[1] < 0) betas[0] = -betas[0];
-    betas[2] = b5[3] / betas[0];
+    if (bs[1] < 0) betas[0] = -betas[0];
+    betas[2] = bs[3] / betas[0];
     betas[3] = 0.0;
   }
   PROF(5);
