@@ -858,7 +858,8 @@ __device__ __forceinline__ double epnp_reproj_term(const double Rv[3][3], const 
 // find_betas variant / Gauss-Newton / R,t / reprojection error.  Returns that variant's error.
 template <typename Ptr>
 __device__ __noinline__ double epnp_minimal(bool active, int variant, const double* pws, const double* us, const EpnpCam cam,
-                                            double Rv[3][3], double tv[3], Ptr ut, Ptr L) {
+                                            double Rv[3][3], double tv[3], Ptr ut, Ptr L, ldsd* Mrows /* PNP_CHUNK x 4 x 24 */,
+                                            int nhyp /* hypotheses in flight: lanes h < nhyp are active */) {
   constexpr int n = 4;
   double cws[4][3], alphas[16], rho[6];
   PROF_DECL;
@@ -882,34 +883,46 @@ __device__ __noinline__ double epnp_minimal(bool active, int variant, const doub
     for (int i = 0; i < n; i++) epnp_alphas(pws + 3 * i, cws, ci, alphas + 4 * i);
     PROF(1);
   }
+  // M^T M (rows 2i, 2i+1 of M; per entry the same k-order as cvMulTransposed: + M1a M1b, + M2a M2b for i = 0..3 from 0.0).
+  // The variant-1 lane of every hypothesis parks its 8 rows of M in LDS, then the 78 upper-triangle entries of all
+  // hypotheses are spread over the 64 lanes (one lane alone, with a read-modify-write of the LDS matrix per term, spent
+  // 160 k cycles here); the result is written into `ut` of its hypothesis, both triangles (symmetric, so it equals the
+  // transposed copy cvSVD would make).
   if (active && variant == 1) {
-    // M^T M accumulated row by row (rows 2i, 2i+1 of M; same k-order as cvMulTransposed), built in
-    // place in `ut` (symmetric, so it equals the transposed copy cvSVD would make)
-    for (int i = 0; i < 144; i++) ut[i] = 0;
+    const int h = threadIdx.x % PNP_CHUNK;
     for (int i = 0; i < n; i++) {
       const double* as = alphas + 4 * i;
       const double u = us[2 * i], v = us[2 * i + 1];
-      double M1[12], M2[12];
+      ldsd* row = Mrows + (h * 4 + i) * 24;
       for (int k = 0; k < 4; k++) {
-        M1[3 * k] = as[k] * cam.fu;
-        M1[3 * k + 1] = 0.0;
-        M1[3 * k + 2] = as[k] * (cam.uc - u);
-        M2[3 * k] = 0.0;
-        M2[3 * k + 1] = as[k] * cam.fv;
-        M2[3 * k + 2] = as[k] * (cam.vc - v);
+        row[3 * k] = as[k] * cam.fu;
+        row[3 * k + 1] = 0.0;
+        row[3 * k + 2] = as[k] * (cam.uc - u);
+        row[12 + 3 * k] = 0.0;
+        row[12 + 3 * k + 1] = as[k] * cam.fv;
+        row[12 + 3 * k + 2] = as[k] * (cam.vc - v);
       }
-      for (int a = 0; a < 12; a++)
-        for (int b = a; b < 12; b++) {
-          double acc = ut[a * 12 + b];
-          acc += M1[a] * M1[b];
-          acc += M2[a] * M2[b];
-          ut[a * 12 + b] = acc;
-        }
     }
-    for (int a = 0; a < 12; a++)
-      for (int b = 0; b < a; b++) ut[a * 12 + b] = ut[b * 12 + a];
-    PROF(2);
   }
+  __syncthreads();
+  for (int t = threadIdx.x; t < nhyp * 78; t += 64) {
+    const int h = t / 78;
+    int q = t - h * 78, a = 0;
+    while (q >= 12 - a) { q -= 12 - a; a++; }
+    const int b = a + q;
+    const ldsd* rows = Mrows + h * 4 * 24;
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      acc += rows[i * 24 + a] * rows[i * 24 + b];
+      acc += rows[i * 24 + 12 + a] * rows[i * 24 + 12 + b];
+    }
+    ldsd* uh = ut.p - (threadIdx.x % PNP_CHUNK) + h;   // hypothesis h's lane-interleaved view of the work area
+    uh[(a * 12 + b) * PNP_CHUNK] = acc;
+    uh[(b * 12 + a) * PNP_CHUNK] = acc;
+  }
+  __syncthreads();
+  PROF(2);
   {
     // 12 x 12 SVD: sweeps with six lanes per hypothesis (lanes h, h + 8, ..., h + 40 share hypothesis h's LDS view),
     // tail on the variant-1 lane
@@ -1202,6 +1215,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
   __shared__ double s_RtRef[12];
   __shared__ double s_mtm[144], s_terms[64 * 9], s_red[64];
   __shared__ int s_modp[PNP_MAXSET], s_modv[PNP_MAXSET], s_draw[PNP_MAXSET];   // general minimal sets (mRansacMinSet != 4)
+  __shared__ double s_Mrows[PNP_CHUNK * 4 * 24];   // rows of M of the chunk's minimal sets (epnp_minimal)
   const int lane = threadIdx.x;
   // persistent waves: the grid may be smaller than the batch (launch_pnp)
   for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
@@ -1338,7 +1352,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
         us[2 * k + 1] = q[1];
       }
       double R[3][3], t[3];
-      const double err = epnp_minimal(active, variant, pws, us, cam, R, t, w_ut, w_L);
+      const double err = epnp_minimal(active, variant, pws, us, cam, R, t, w_ut, w_L, LDS_PTR(s_Mrows), nact);
       // N = 1; if (e2 < e1) N = 2; if (e3 < e[N]) N = 3   (src/PnPsolver.cc:385-389)
       const double e1 = __shfl(err, hyp), e2 = __shfl(err, hyp + PNP_CHUNK), e3 = __shfl(err, hyp + 2 * PNP_CHUNK);
       int win = 1;
@@ -1515,6 +1529,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
 __global__ void k_epnp_debug(int n, const double* pws, const double* us, double* work, EpnpCam cam, double* out13) {
   __shared__ double s_work[PNP_CHUNK * (156 + 60)];
   __shared__ double s_mtm[144], s_terms[64 * 9], s_red[64], s_Rt[12];
+  __shared__ double s_Mrows[PNP_CHUNK * 4 * 24];
   const int lane = threadIdx.x;
   const LArr ut{LDS_PTR(s_work)}, L{LDS_PTR(s_work) + 156 * PNP_CHUNK};
   double e;
@@ -1524,7 +1539,8 @@ __global__ void k_epnp_debug(int n, const double* pws, const double* us, double*
     for (int i = 0; i < 8; i++) u[i] = us[i];
     const int hyp = lane % PNP_CHUNK, variant = lane / PNP_CHUNK + 1;
     const bool active = hyp == 0 && variant <= 3;
-    const double err = epnp_minimal(active, variant, p, u, cam, R, t, ut, L);
+    const LArr h_ut{LDS_PTR(s_work) + hyp}, h_L{LDS_PTR(s_work) + 156 * PNP_CHUNK + hyp};   // per-hypothesis views, as in k_pnp
+    const double err = epnp_minimal(active, variant, p, u, cam, R, t, h_ut, h_L, LDS_PTR(s_Mrows), 1);
     const double e1 = __shfl(err, 0), e2 = __shfl(err, PNP_CHUNK), e3 = __shfl(err, 2 * PNP_CHUNK);
     int win = 1;
     e = e1;
