@@ -1,0 +1,133 @@
+"""Regression tests for the round-1 advisor findings: the rotation-event list of k_match when the map holds
+more points than the frame has keypoints, the extractor handle after a failed geometry change, the tracker behind an
+extraction replayed as a hipGraph, and the validation of host-supplied octaves."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from sdslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+K = (synth.FX, synth.FY, synth.CX, synth.CY)
+BOUNDS = (0.0, 640.0, 0.0, 480.0)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import sdslam_amd
+    if sdslam_amd.device_count() < 1:
+        pytest.fail("no HIP device: the gpu-marked tests need a real MI355X")
+    return sdslam_amd
+
+
+def test_more_map_points_than_keypoints_with_overwrites(sd, oracle):
+    """max_points (1000) > keypoint capacity (400-feature extractor, KP2 = 512): ~900 valid last-frame points with
+    Observations() == 0 overwrite each other's assignments, so the rotation histogram records more events than there are
+    keypoints (one per ASSIGNMENT, src/ORBmatcher.cc:1045-1052)."""
+    s = synth.make_scene(31)
+    cfg_small, cfg_big = (400, 1.2, 8, 20), (1000, 1.2, 8, 20)
+    cur, ref = sd.ORBextractor(*cfg_small, 640, 480, 1), sd.ORBextractor(*cfg_small, 640, 480, 1)
+    ck, cd, cn = cur.extract_batch(s["cur"][None])
+    ref.extract_batch(s["ref"][None])
+    big = oracle.OrbOracle(*cfg_big)
+    rk, rd = big.extract(s["ref"])                                   # the map: 1000 points seen in the last frame
+    last = synth.tracking_case(31, rk, rd, max_points=900)
+    last["obs"][:] = 0                                               # nothing is ever "claimed": later points overwrite
+    # three copies of every point a few centimetres apart: they land in the same windows and fight for the same keypoints
+    for k in ("valid", "Xw", "desc", "octave", "angle", "obs"):
+        last[k] = np.concatenate([last[k][:330]] * 3 + [last[k][990:]])[:1000]
+    last["Xw"] = last["Xw"] + np.random.default_rng(1).normal(size=last["Xw"].shape) * 0.004
+    assert int(last["valid"].sum()) > cur.cap
+    trk = sd.Tracker(cur, ref, max_points=1000, max_batch=1, pnp_max_iterations=8)
+    trk.set_camera(*K, 0.0, BOUNDS)
+    trk.set_last(0, [last])
+    tab = oracle.OrbOracle(*cfg_small).tables()
+    n = cn[0]
+    for th, ori in ((8.0, True), (30.0, True), (30.0, False)):
+        trk.set_poses(0, [s["T_ref"]], [s["T_cur"]])
+        trk.match(1, th, True, ori)
+        cm, nm = trk.get_matches(0, 1)
+        on, ocm = oracle.search_by_projection(ck[0, :n], cd[0, :n], tab["sf"], BOUNDS, K, s["T_cur"], s["T_ref"], last, th=th, check_ori=ori)
+        assert nm[0] == on and np.array_equal(cm[0, :n], ocm), (th, ori, nm[0], on)
+    assert on > 100
+
+
+def test_extractor_survives_a_failed_geometry_change(sd, oracle):
+    img = synth.make_image(5)
+    ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 1)
+    k0, d0 = ext(img)
+    k_tiny, _ = ext(np.full((2, 2), 7, np.uint8))   # a legal geometry (every level keeps >= 1 pixel) without a single corner
+    assert len(k_tiny) == 0
+    with pytest.raises(sd.SdError):
+        ext(np.full((1, 1), 7, np.uint8))          # level sizes collapse to zero: refused, nothing may be left half-built
+    k1, d1 = ext(img)
+    assert np.array_equal(k0, k1) and np.array_equal(d0, d1)
+    ok, od = oracle.OrbOracle(1000, 1.2, 8, 20).extract(img)
+    assert np.array_equal(k1, ok) and np.array_equal(d1, od)
+    k2, d2 = ext(synth.make_image(6, 320, 240))     # and a real geometry change still works afterwards
+    ok2, od2 = oracle.OrbOracle(1000, 1.2, 8, 20).extract(synth.make_image(6, 320, 240))
+    assert np.array_equal(k2, ok2) and np.array_equal(d2, od2)
+
+
+def test_invalid_octave_is_refused(sd):
+    s = synth.make_scene(20)
+    cur, ref = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 1), sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 1)
+    cur.extract_batch(s["cur"][None])
+    rk, rd, rn = ref.extract_batch(s["ref"][None])
+    trk = sd.Tracker(cur, ref, 1000, 1, 8)
+    last = synth.tracking_case(20, rk[0, :rn[0]], rd[0, :rn[0]])
+    last["octave"][5] = 8                            # nlevels = 8: valid octaves are 0..7
+    with pytest.raises(sd.SdError):
+        trk.set_last(0, [last])
+    last["octave"][5] = -1
+    with pytest.raises(sd.SdError):
+        trk.set_last(0, [last])
+    last["valid"][5] = 0                             # an invalid entry's octave is never used
+    trk.set_last(0, [last])
+
+
+CHILD = r'''
+import os, sys, numpy as np
+sys.path.insert(0, ROOT)
+import sdslam_amd
+from sdslam_amd import synth
+from sdslam_amd.capi import DeviceBuffer
+K = (synth.FX, synth.FY, synth.CX, synth.CY)
+s = [synth.make_scene(20 + i) for i in range(2)]
+cur, ref = sdslam_amd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2), sdslam_amd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2)
+rk, rd, rn = ref.extract_batch(np.stack([x["ref"] for x in s]))
+trk = sdslam_amd.Tracker(cur, ref, 1000, 2, 200)
+trk.set_camera(*K, 0.0, (0.0, 640.0, 0.0, 480.0))
+trk.set_last(0, [synth.tracking_case(i, rk[i, :rn[i]], rd[i, :rn[i]]) for i in range(2)])
+trk.set_poses(0, [x["T_ref"] for x in s], [synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04)) @ x["T_cur"] for x in s])
+trk.set_rand(0, np.tile(synth.glibc_rand_stream(800), (2, 1)))
+fr = np.stack([x["cur"] for x in s])
+d = DeviceBuffer(fr.nbytes); d.upload(fr)
+for _ in range(3):                      # replayed graph from the second call on
+    cur.extract_batch_device(d.ptr, 2, 640, 480)
+    trk.align(2, 0); trk.match(2, 8.0, True, True); trk.pnp(2, 0.99, 10, 200, 4, 0.28, 5.991, 200)
+al, (cm, nm), pn = trk.get_align(0, 2), trk.get_matches(0, 2), trk.get_pnp(0, 2)
+np.savez(sys.argv[1], T=np.stack(al["T"]), iters=al["iters"], cm=cm, nm=nm, pT=pn["T"], inl=pn["inliers"])
+'''
+
+
+def test_tracker_behind_graph_replayed_extraction(tmp_path):
+    """SD_USE_GRAPH=1: inside a captured graph the pyramid-done event is a graph node, not an event record; the tracker's
+    early start (ImageAlign right behind the pyramid) must then wait for the whole extraction.  Fresh child processes (the
+    switch is read once): identical results with and without the graph."""
+    outs = []
+    for flag in ("0", "1"):
+        out = tmp_path / f"g{flag}.npz"
+        env = dict(os.environ)
+        env.pop("SD_USE_GRAPH", None)
+        if flag == "1":
+            env["SD_USE_GRAPH"] = "1"
+        r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + CHILD, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(np.load(out))
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k

@@ -94,6 +94,48 @@ def test_image_align_modes(sd, oracle, rig):
             assert abs(g["error"][i] - r["error"]) <= 1e-7 * max(1.0, abs(r["error"]))
 
 
+def test_image_align_ragged_point_counts(sd, oracle, rig):
+    """Point counts that fill neither the 100-point (modes 2, 3) nor the 300-point (modes 0, 1) capacity, scattered validity
+    flags, and one frame with just eight points: the input class behind the device fault of round 1 (a development build of
+    k_align read the per-point LDS projections of slots beyond the gathered points -- uninitialised coordinates -- and
+    used them as image addresses).  Every thread of the current kernel owns one point and idles when
+    it has none; this test pins that for all four modes."""
+    trk, B = rig["trk"], rig["B"]
+    rng = np.random.default_rng(4)
+    # (fewer than three points make H rank deficient: there the reference's own result is decided by the rounding of its
+    # per-pixel accumulation order, which no parallel sum reproduces -- DESIGN.md section 3; not a parity case)
+    counts = [37, 8, 101, 299]
+    cases = []
+    for i in range(B):
+        c = {k: v.copy() for k, v in rig["oras"][i]["last"].items()}
+        idx = np.flatnonzero(c["valid"])
+        keep = rng.choice(idx, size=counts[i], replace=False)
+        c["valid"][:] = 0
+        c["valid"][keep] = 1
+        cases.append(c)
+    trk.set_last(0, cases)
+    try:
+        T0 = [synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04)) @ s["T_cur"] for s in rig["scenes"]]
+        for mode in (0, 1, 2, 3):
+            Tinit = T0 if mode < 2 else [np.eye(4) for _ in range(B)]
+            trk.set_poses(0, [s["T_ref"] for s in rig["scenes"]], Tinit)
+            trk.align(B, mode=mode)
+            g = trk.get_align(0, B)
+            for i in range(B):
+                o = rig["oras"][i]
+                pc = [o["oc"].level(l) for l in range(8)]
+                pr = [o["orf"].level(l) for l in range(8)]
+                Xw = cases[i]["Xw"][cases[i]["valid"] != 0]
+                r = oracle.align(pc, pr, o["tab"]["inv_sf"], o["tab"]["sf"], Xw, rig["scenes"][i]["T_ref"], Tinit[i], K, mode=mode)
+                assert g["ok"][i] == r["ok"] and np.array_equal(g["iters"][i][:8], r["iters"]), (mode, i, g["iters"][i][:8], r["iters"])
+                if r["ok"] and mode != 3:
+                    assert np.abs(g["T"][i] - r["T"]).max() <= POSE_TOL, (mode, i)
+                else:
+                    assert np.abs(g["T"][i] - Tinit[i]).max() == 0
+    finally:
+        trk.set_last(0, [o["last"] for o in rig["oras"]])
+
+
 def test_search_by_projection_bit_exact(sd, oracle, rig):
     trk, B = rig["trk"], rig["B"]
     # th = 64: windows of hundreds of pixels overflow the LDS candidate list (per-point slow path of the kernel)
