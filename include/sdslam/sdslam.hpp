@@ -214,6 +214,18 @@ class ORBmatcher {
     check(sd_track_get_local(batch.handle(), frame, 1, local_match.data(), kp_cap, &n, nullptr, nullptr, nullptr, nullptr));
     return n;
   }
+  // int SearchByPoints(KeyFrame* currentKF, KeyFrame* pKF, vector<MapPoint*>& matches) (src/ORBmatcher.h:56, brute-force
+  // Hamming; LoopClosing::ComputeSim3): has_mp_* = GetMapPointMatches()[i] != NULL && !isBad(), n flags per keyframe
+  void SearchByPoints(TrackBatch& batch, int n_frames, const uint8_t* has_mp_cur, const uint8_t* has_mp_ref, int n) {
+    check(sd_track_set_point_flags(batch.handle(), 0, n_frames, has_mp_cur, has_mp_ref, n));
+    check(sd_track_search_by_points(batch.handle(), n_frames, mfNNratio, mbCheckOrientation ? 1 : 0));
+  }
+  int PointsResult(TrackBatch& batch, int frame, std::vector<int32_t>& matches12, int kp_cap) {
+    matches12.resize(kp_cap);
+    int32_t n = 0;
+    check(sd_track_get_point_matches(batch.handle(), frame, 1, matches12.data(), kp_cap, &n));
+    return n;
+  }
   int Result(TrackBatch& batch, int frame, std::vector<int32_t>& mvpMapPoints, int kp_cap) {
     mvpMapPoints.resize(kp_cap);
     int32_t n = 0;
@@ -299,6 +311,121 @@ class LoopClosing {
   }
 };
 
+// ------------------------------------------------------------------------------------------------------------------
+// Drop-in overloads on the reference's OWN Frame / MapPoint types: the call sites of
+// src/Tracking.cc:668-693 keep their arguments -- `image_align.ComputePose(mCurrentFrame, mLastFrame)`,
+// `matcher.SearchByProjection(mCurrentFrame, mLastFrame, th, bMono)`, `Optimizer::PoseOptimization(&mCurrentFrame)` --
+// and the SoA flattening of INTEGRATION.md section 3 happens in here.  FrameT / its map-point type only need the reference's
+// member names (src/Frame.h, src/MapPoint.h): N, mvpMapPoints, mvbOutlier, mvKeys, mvKeysUn, GetPose(), SetPose(),
+// static fx fy cx cy mnMinX mnMaxX mnMinY mnMaxY, mbf; GetWorldPos() (indexable by (k)), GetDescriptor() (with .data),
+// Observations(), isBad().  One FrameTracker per camera: `cur` holds the extraction of the current frame, `last` that of the
+// previous one (the shimmed ORBextractor of INTEGRATION.md section 3 fills them from Frame's constructor; swap per frame).
+class FrameTracker {
+ public:
+  FrameTracker(ORBextractor& cur, ORBextractor& last, int max_points = 2048, int pnp_max_iterations = 300)
+      : batch_(cur, last, max_points, 1, pnp_max_iterations), max_points_(max_points) {}
+  TrackBatch& batch() { return batch_; }
+
+  // bool ImageAlign::ComputePose(Frame &CurrentFrame, const Frame &LastFrame)          src/ImageAlign.h:36, src/Tracking.cc:668
+  template <class FrameT>
+  bool ComputePose(FrameT& CurrentFrame, const FrameT& LastFrame, double* error = nullptr) {
+    Upload(CurrentFrame, LastFrame);
+    check(sd_track_align(batch_.handle(), 1, 0));
+    double T[16];
+    int32_t ok = 0;
+    check(sd_track_get_align(batch_.handle(), 0, 1, T, error, &ok, nullptr, nullptr));
+    if (ok) SetPoseOf(CurrentFrame, T);
+    return ok != 0;
+  }
+  // int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+  //                                                                                     src/ORBmatcher.h:46, src/Tracking.cc:677
+  template <class FrameT>
+  int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, float th, bool bMono, bool checkOrientation = true) {
+    Upload(CurrentFrame, LastFrame);
+    check(sd_track_match(batch_.handle(), 1, th, bMono ? 1 : 0, checkOrientation ? 1 : 0));
+    std::vector<int32_t> idx(CurrentFrame.N > 0 ? cap(CurrentFrame) : 1);
+    int32_t n = 0;
+    check(sd_track_get_matches(batch_.handle(), 0, 1, idx.data(), (int)idx.size(), &n));
+    for (int i = 0; i < CurrentFrame.N; i++)
+      if (idx[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[idx[i]];   // the search only ever ASSIGNS
+    return n;
+  }
+  // int Optimizer::PoseOptimization(Frame *pFrame)                                       src/Optimizer.h, src/Tracking.cc:693
+  // on whatever pFrame->mvpMapPoints holds (keypoint i <-> map point i; sd_track_set_matches)
+  template <class FrameT>
+  int PoseOptimization(FrameT* pFrame) {
+    FrameT& F = *pFrame;
+    SetCameraOf(F);
+    LastFrameView v;
+    std::vector<int32_t> cm((size_t)F.N, -1);
+    v.valid.assign(F.N, 0); v.Xw.assign((size_t)F.N * 3, 0.0); v.desc.assign((size_t)F.N * 32, 0);
+    v.octave.assign(F.N, 0); v.angle.assign(F.N, 0.f); v.obs.assign(F.N, 0);
+    for (int i = 0; i < F.N; i++) {
+      auto* p = F.mvpMapPoints[i];
+      if (!p) continue;
+      v.valid[i] = 1;
+      cm[i] = i;
+      const auto X = p->GetWorldPos();
+      for (int k = 0; k < 3; k++) v.Xw[(size_t)i * 3 + k] = X(k);
+      v.obs[i] = p->Observations();
+    }
+    batch_.SetLastFrame(0, v);
+    const auto Tc = F.GetPose();
+    check(sd_track_set_poses(batch_.handle(), 0, 1, Tc.data(), Tc.data()));
+    check(sd_track_set_matches(batch_.handle(), 0, 1, cm.data(), F.N));
+    check(sd_track_pose_opt(batch_.handle(), 1, 0));
+    std::vector<uint8_t> outl(cap(F));
+    double T[16];
+    int32_t info[8];
+    check(sd_track_get_pose_opt(batch_.handle(), 0, 1, T, outl.data(), (int)outl.size(), info));
+    SetPoseOf(F, T);
+    for (int i = 0; i < F.N; i++)
+      if (F.mvpMapPoints[i]) F.mvbOutlier[i] = outl[i] != 0;
+    return info[5];
+  }
+
+ private:
+  template <class FrameT>
+  int cap(const FrameT& F) { return F.N > max_points_ ? F.N : max_points_; }
+  template <class FrameT>
+  void SetCameraOf(const FrameT& F) {
+    batch_.SetCamera(FrameT::fx, FrameT::fy, FrameT::cx, FrameT::cy, F.mbf, FrameT::mnMinX, FrameT::mnMaxX, FrameT::mnMinY, FrameT::mnMaxY);
+  }
+  template <class FrameT>
+  static void SetPoseOf(FrameT& F, const double T[16]) {
+    auto M = F.GetPose();                      // Eigen::Matrix4d: 16 doubles column-major behind data()
+    for (int i = 0; i < 16; i++) M.data()[i] = T[i];
+    F.SetPose(M);
+  }
+  // what TrackWithMotionModel reads of mLastFrame (src/ImageAlign.cc:64-72, src/ORBmatcher.cc:968-1042) + both poses
+  template <class FrameT>
+  void Upload(const FrameT& CurrentFrame, const FrameT& LastFrame) {
+    SetCameraOf(CurrentFrame);
+    LastFrameView v;
+    const int n = LastFrame.N;
+    v.valid.assign(n, 0); v.Xw.assign((size_t)n * 3, 0.0); v.desc.assign((size_t)n * 32, 0);
+    v.octave.assign(n, 0); v.angle.assign(n, 0.f); v.obs.assign(n, 0);
+    for (int i = 0; i < n; i++) {
+      v.octave[i] = LastFrame.mvKeys[i].octave;
+      v.angle[i] = LastFrame.mvKeysUn[i].angle;
+      auto* p = LastFrame.mvpMapPoints[i];
+      if (!p || LastFrame.mvbOutlier[i]) continue;
+      v.valid[i] = 1;
+      const auto X = p->GetWorldPos();
+      for (int k = 0; k < 3; k++) v.Xw[(size_t)i * 3 + k] = X(k);
+      const auto D = p->GetDescriptor();
+      for (int k = 0; k < 32; k++) v.desc[(size_t)i * 32 + k] = D.data[k];
+      v.obs[i] = p->Observations();
+    }
+    batch_.SetLastFrame(0, v);
+    const auto Tl = LastFrame.GetPose();
+    const auto Tc = CurrentFrame.GetPose();
+    check(sd_track_set_poses(batch_.handle(), 0, 1, Tl.data(), Tc.data()));
+  }
+  TrackBatch batch_;
+  int max_points_;
+};
+
 class PnPsolver {
  public:
   PnPsolver() { SetRansacParameters(); }
@@ -311,6 +438,12 @@ class PnPsolver {
   void iterate(TrackBatch& batch, int n_frames, int nIterations, const int32_t* rand_values, int per_frame) {
     check(sd_track_set_rand(batch.handle(), 0, n_frames, rand_values, per_frame));
     check(sd_track_pnp(batch.handle(), n_frames, p_, minInl_, maxIts_, minSet_, eps_, th2_, nIterations));
+  }
+  // a further iterate(nIterations) on the same solvers (mnIterations and the best hypothesis carry over, src/PnPsolver.cc:177)
+  void iterateAgain(TrackBatch& batch, int n_frames, int nIterations) { check(sd_track_pnp_iterate(batch.handle(), n_frames, nIterations)); }
+  // PnPsolver(F, vpMapPointMatches) on a match vector of the caller's (indices into the last-frame arrays, -1 = NULL)
+  static void SetMatches(TrackBatch& batch, int frame, const int32_t* vpMapPointMatches, int n) {
+    check(sd_track_set_matches(batch.handle(), frame, 1, vpMapPointMatches, n));
   }
   // Tcw: 4x4 CV_32F row-major; returns false for the reference's empty cv::Mat
   bool Result(TrackBatch& batch, int frame, float Tcw[16], bool& bNoMore, std::vector<uint8_t>& vbInliers, int& nInliers, int kp_cap) {

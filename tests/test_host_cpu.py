@@ -151,3 +151,15 @@ def test_cpp_facade_compiles_and_links(sd):
                            "-L", libdir, "-lsdslam_hip", f"-Wl,-rpath,{libdir}"])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "facade ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+def test_cpp_frame_overloads_compile_on_reference_shaped_types(sd):
+    """The Frame&-style overloads (FrameTracker in sdslam.hpp) instantiate on stand-ins for the reference's Frame /
+    MapPoint / Eigen / cv::Mat types: the call sites of src/Tracking.cc:668-693 need a type alias, not a rewrite."""
+    exe = "/tmp/sd_facade_frame_check"
+    libdir = os.path.dirname(sd.lib_path())
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "facade_frame.cc"), "-o", exe,
+                           "-L", libdir, "-lsdslam_hip", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "facade frame ok" in out.stdout, (out.returncode, out.stdout, out.stderr)

@@ -131,3 +131,51 @@ def test_tracker_behind_graph_replayed_extraction(tmp_path):
         outs.append(np.load(out))
     for k in outs[0].files:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_cpp_frame_overloads_run_the_motion_model_body(sd, oracle, tmp_path):
+    """The C++ drop-in path end to end on the GPU: tests/native/facade_frame.cc (reference-shaped Frame / MapPoint types
+    through FrameTracker::ComputePose / SearchByProjection / PoseOptimization, i.e. src/Tracking.cc:668-693) against the
+    oracle on the same two frames."""
+    import struct
+    s = synth.make_scene(20)
+    cfg = (1000, 1.2, 8, 20)
+    oc, orf = oracle.OrbOracle(*cfg), oracle.OrbOracle(*cfg)
+    ck, cd = oc.extract(s["cur"])
+    rk, rd = orf.extract(s["ref"])
+    last = synth.tracking_case(20, rk, rd)
+    T0 = synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04)) @ s["T_cur"]
+    raw = tmp_path / "frames.bin"
+    with open(raw, "wb") as f:
+        f.write(s["cur"].tobytes())
+        f.write(s["ref"].tobytes())
+        f.write(np.ascontiguousarray(s["T_ref"].T).tobytes())
+        f.write(np.ascontiguousarray(T0.T).tobytes())
+        idx = np.flatnonzero(last["valid"])
+        f.write(struct.pack("<i", len(idx)))
+        for i in idx:
+            f.write(struct.pack("<i3d", int(i), *last["Xw"][i]))
+    exe = str(tmp_path / "facade_frame")
+    libdir = os.path.dirname(sd.lib_path())
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-DRUN_ON_GPU", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "facade_frame.cc"), "-o", exe, "-L", libdir, "-lsdslam_hip",
+                           f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([exe, str(raw)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-2000:])
+    res = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    mat = [l for l in out.stdout.splitlines() if l.startswith("MATCH")][0].split()[1:]
+    N, nmatches, ngood, nout = (int(v) for v in res[1:5])
+    T = np.array([float(v) for v in res[5:21]]).reshape(4, 4).T
+    got_match = np.array([int(v) for v in mat], np.int32)
+    # the oracle's composition of the same three calls
+    tab = oc.tables()
+    al = oracle.align([oc.level(l) for l in range(8)], [orf.level(l) for l in range(8)], tab["inv_sf"], tab["sf"],
+                      last["Xw"][last["valid"] != 0], s["T_ref"], T0, K, 0)
+    Ta = al["T"] if al["ok"] else T0
+    nm, cm = oracle.search_by_projection(ck, cd, tab["sf"], BOUNDS, K, Ta, s["T_ref"], last, th=8.0)
+    Xw = np.zeros((len(ck), 3))
+    Xw[cm >= 0] = last["Xw"][cm[cm >= 0]]
+    po = oracle.pose_optimization(ck, cm >= 0, Xw, tab["inv_sigma2"], K, Ta)
+    assert N == len(ck) and nmatches == nm and np.array_equal(got_match, cm)
+    assert ngood == po["n_inliers"] and nout == int(po["outlier"][cm >= 0].sum())
+    assert np.abs(T - po["T"]).max() <= 1e-5
