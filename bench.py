@@ -53,9 +53,12 @@ W, H = 640, 480
 BOUNDS = (0.0, 640.0, 0.0, 480.0)
 PNP = dict(probability=0.99, min_inliers=10, max_iterations=200, min_set=4, epsilon=0.28, th2=5.991)
 RECORD_SOURCE = {"pnp": 0, "poseopt": 1, "motion_model": 2, "track": 3}
-# Vector-ALU issue model (measured by tools/valu_microbench.py on this GPU): one wave64 VALU instruction
-# occupies a SIMD for VALU_CYCLES cycles once >= 2 waves are resident; 256 CUs x 4 SIMDs at CLK_GHZ.
-N_SIMD, CLK_GHZ, VALU_CYCLES = 1024, 2.4, 2.0
+# Vector-ALU issue model (measured with tools/valu_microbench.hip on an MI355X, profiles/r02_valu_microbench.json,
+# 8 waves per SIMD, every CU busy): a wave64 VOP2 instruction (v_add_u32, v_subrev) occupies a SIMD for 2.6 cycles, a VOP3
+# instruction with three sources -- v_max3_i32, v_min3_i32, v_perm_b32, v_alignbyte_b32, v_and_or_b32, v_mad_i32_i24, which is
+# what the FAST / pyramid / matcher kernels are made of -- for 4.2, v_pk_max_u16 / v_bcnt 4.3-4.5 (one wave alone: 5.4 for
+# all of them).  256 CUs x 4 SIMDs at CLK_GHZ.
+N_SIMD, CLK_GHZ, VALU_CYCLES_VOP2, VALU_CYCLES_VOP3 = 1024, 2.4, 2.6, 4.2
 
 
 def _scene(args):
@@ -217,8 +220,10 @@ def pmc_for_stage(stage, batch):
     if not found:
         return None, None
     sc = batch / PMC_FRAMES
-    min_ms = valu * sc / N_SIMD * VALU_CYCLES / (CLK_GHZ * 1e9) * 1e3
-    return tot * sc, {"wave_insts_per_step": valu * sc, "cycles_per_inst": VALU_CYCLES, "min_ms_at_full_issue": min_ms,
+    lo_ms = valu * sc / N_SIMD * VALU_CYCLES_VOP2 / (CLK_GHZ * 1e9) * 1e3
+    hi_ms = valu * sc / N_SIMD * VALU_CYCLES_VOP3 / (CLK_GHZ * 1e9) * 1e3
+    return tot * sc, {"wave_insts_per_step": valu * sc, "cycles_per_inst_measured": {"vop2": VALU_CYCLES_VOP2, "vop3_three_source": VALU_CYCLES_VOP3},
+                      "min_ms_if_all_vop2": lo_ms, "min_ms_if_all_vop3": hi_ms, "min_ms_at_full_issue": lo_ms,
                       "profiled_kernel_ms": dur * sc / 1e6, "source": os.path.basename(files[-1])}
 
 
@@ -460,11 +465,19 @@ def main():
 
     import torch
     dist = None
+    # SD_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo over host memory -- a way to run the N > 1 control flow (rank spawn,
+    # shards, per-step gather, max over ranks) on a one-GPU box.  Never a measurement: the line says so.
+    rehearsal = bool(os.environ.get("SD_BENCH_REHEARSAL")) and world > 1
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev = torch.device("cuda", local_rank)
 
@@ -484,13 +497,18 @@ def main():
         wl.step()
         if dist is not None and not args.orb_only:
             trk.stream_fence(stream, 0)          # the collective waits for the records
-            dist_util.all_gather_records(rec[k % 2], gathered[k % 2], dist)
+            if rehearsal:                        # gloo: host tensors (the stream fence orders the copy behind the pack kernel)
+                gathered[k % 2].copy_(dist_util.all_gather_records(rec[k % 2].cpu(), torch.zeros((B * world, dist_util.RECORD_F64), dtype=torch.float64), dist))
+            else:
+                dist_util.all_gather_records(rec[k % 2], gathered[k % 2], dist)
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    red_dev = None if rehearsal else dev
 
     for k in range(args.warmup):
         full_step(k)
@@ -512,7 +530,7 @@ def main():
         trk_ms[1:] *= 2      # the timers average per call; search and PoseOptimization run twice per step here
     cur.set_profiling(False)
     trk.set_profiling(False)
-    dt = dist_util.max_over_ranks(dt, dist, dev)                      # MAX over ranks
+    dt = dist_util.max_over_ranks(dt, dist, red_dev)                  # MAX over ranks
 
     # ---- check what was gathered: every rank's block of the last step equals that rank's own records
     last = (args.steps - 1) % 2
@@ -560,7 +578,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "pose_solver": args.pose_solver,
                        "frames_per_gpu_per_step": B, "unique_scenes": nu, "inputs": "resident in HBM", "timed_region_s": dt,
-                       "pose_records": ("all-gathered over RCCL every step inside the timed region, straight from the device buffer the "
+                       "pose_records": ("REHEARSAL ONLY (SD_BENCH_REHEARSAL): all ranks on one GPU, gloo over host memory -- not a measurement" if rehearsal else
+                                        "all-gathered over RCCL every step inside the timed region, straight from the device buffer the "
                                         "last tracking kernel wrote") if world > 1 else "packed on the device every step (single GPU: no collective)"},
             "stages_ms_per_step": {nm_: float(ms) for nm_, ms in zip(names, stage_ms)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -569,7 +588,8 @@ def main():
                          "note": "integer/byte kernel limited by vector-ALU issue, not HBM (DESIGN.md section 6); traffic = HBM bytes per "
                                  "step from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/), scaled to this batch",
                          "valu": valu,
-                         "valu_frac": (valu["min_ms_at_full_issue"] / float(stage_ms[dom])) if valu else None},
+                         "valu_frac": (valu["min_ms_if_all_vop2"] / float(stage_ms[dom])) if valu else None,
+                         "valu_frac_at_vop3_rate": (valu["min_ms_if_all_vop3"] / float(stage_ms[dom])) if valu else None},
             "tracking": {"align_ok": int(al["ok"].sum()), "mean_gn_iterations": its, "mean_matches": float(nm.mean()),
                          "pnp_ok": int(np.asarray(pn["ok"]).sum()), "mean_pnp_inliers": float(pn["n_inliers"].mean()),
                          "mean_pnp_iterations": float(pn["iterations"].mean()), "align_translation_err_m": terr},

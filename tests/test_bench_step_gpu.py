@@ -122,3 +122,25 @@ def test_tracking_step_1280x720(oracle):
         ora = [_oracle_scene(oracle, wl, i, solver, bounds, bench.CFG) for i in range(2)]
         _compare(wl, ora, solver, rec_host)
         assert all(o["al"]["ok"] for o in ora) and min(o["nm"] for o in ora) >= 100
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py's N > 1 control flow on this one-GPU box: `--gpus 2` spawns two ranks (both on GPU 0, gloo over host memory:
+    SD_BENCH_REHEARSAL), every step packs the records on the device and gathers them inside the timed region, rank 0 checks
+    its own block of the gathered tensor against its records and prints one line.  (The RCCL leg itself -- device tensors
+    straight into all_gather_into_tensor -- needs two GPUs; the same call is exercised on CPU tensors in
+    tests/test_multi_rank_cpu.py.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SD_BENCH_REHEARSAL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "64",
+                        "--unique", "4", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["frames_per_gpu_per_step"] == 64 and "REHEARSAL" in line["config"]["pose_records"]
+    assert line["tracking"]["pnp_ok"] == 64 and line["value"] > 0
