@@ -204,6 +204,22 @@ __device__ __forceinline__ void se3_exp(const ldsd* upd, ldsd* res, ldsd* tmp) {
   NOUNROLL for (int i = 0; i < 3; i++) res[i * 4 + 3] = V[i * 3] * u0 + V[i * 3 + 1] * u1 + V[i * 3 + 2] * u2;
 }
 
+// The serial step of an iteration: x = H.ldlt().solve(Jres), E = Exp(-x); returns AbsMax(x).  A FUNCTION CALL on purpose: its
+// register needs (the unrolled LDLT) stay out of the kernel's allocation, and what the caller has to preserve around the call
+// is saved inside the one-lane branch the call sits in -- as inline code the same registers were spilled by every lane, every
+// iteration (350 MB of scratch writes per 1024-frame launch).
+__device__ __noinline__ double solve_and_exp(ldsd* H, const ldsd* b, ldsd* x, ldsd* nx, ldsd* E, ldsd* tmp, ldsi* tr) {
+  ldlt_solve6(H, b, x, tmp, tr);
+  double mx = -1;
+  NOUNROLL for (int i = 0; i < 6; i++) {
+    const double xi = x[i];
+    nx[i] = -xi;
+    if (fabs(xi) > mx) mx = fabs(xi);
+  }
+  se3_exp(nx, E, tmp);
+  return mx;
+}
+
 // One THREAD per point (its 16 patch pixels), AL_PT_THREADS = 320 threads per frame pair.
 //
 // What a thread keeps in registers for a whole level is small: the 7 x 8 BYTES of the reference image around its point
@@ -324,9 +340,7 @@ __global__ __launch_bounds__(AL_PT_THREADS, MINW) void k_align(const OrbPlan* __
   __syncthreads();
 
   // the thread's point (threads >= npts idle through the per-point parts)
-  const bool has_pt = tid < npts;
-  double p0 = 0, p1 = 0, p2 = 0;
-  if (has_pt) { p0 = s_pts[tid * 3]; p1 = s_pts[tid * 3 + 1]; p2 = s_pts[tid * 3 + 2]; }
+  const bool has_pt = tid < npts;   // its world point stays in s_pts (three LDS reads per projection instead of six registers)
   bool vis = false;                         // visible_pts_[pt]: only ever set
   // patch_cache_ row of the point, as what it is computed from: reference pixels (uf-3 .. uf+4) x (vf-3 .. vf+3) and the
   // bilinear weights (survives a level in which the point is clipped, like the reference's cache row)
@@ -377,6 +391,7 @@ __global__ __launch_bounds__(AL_PT_THREADS, MINW) void k_align(const OrbPlan* __
 
     // ------------------------------------------------ PrecomputePatches (src/ImageAlign.cc:355-421), once per level
     if (has_pt) {
+      const double p0 = s_pts[tid * 3], p1 = s_pts[tid * 3 + 1], p2 = s_pts[tid * 3 + 2];
       double xc[3];
       for (int i = 0; i < 3; i++) xc[i] = (s_last[i * 4] * p0 + s_last[i * 4 + 1] * p1 + s_last[i * 4 + 2] * p2) + s_last[i * 4 + 3];
       const double invzc = 1.0 / xc[2];
@@ -455,6 +470,7 @@ __global__ __launch_bounds__(AL_PT_THREADS, MINW) void k_align(const OrbPlan* __
       bool measured = false;
       float4* c4w = (float4*)(s_chi + (has_pt ? tid : 0) * 16);
       if (has_pt && vis) {
+        const double p0 = s_pts[tid * 3], p1 = s_pts[tid * 3 + 1], p2 = s_pts[tid * 3 + 2];
         double xc[3];
         for (int i = 0; i < 3; i++) xc[i] = (s_pose[i * 4] * p0 + s_pose[i * 4 + 1] * p1 + s_pose[i * 4 + 2] * p2) + s_pose[i * 4 + 3];
         const double invzc = 1.0 / xc[2];
@@ -595,17 +611,7 @@ __global__ __launch_bounds__(AL_PT_THREADS, MINW) void k_align(const OrbPlan* __
           for (int w = 1; w < AL_PT_WAVES; w++) v += s_red[w][21 + a];
           s_b[a] = v;
         }
-        if (lane == 0) {
-          ldlt_solve6(LDSD(s_H), LDSD(s_b), LDSD(s_x), LDSD(s_tmp), (ldsi*)s_tr);
-          double mx = -1;
-          NOUNROLL for (int i = 0; i < 6; i++) {
-            const double xi = s_x[i];
-            s_nx[i] = -xi;
-            if (fabs(xi) > mx) mx = fabs(xi);
-          }
-          se3_exp(LDSD(s_nx), LDSD(s_E), LDSD(s_tmp));
-          s_mx = mx;
-        }
+        if (lane == 0) s_mx = solve_and_exp(LDSD(s_H), LDSD(s_b), LDSD(s_x), LDSD(s_nx), LDSD(s_E), LDSD(s_tmp), (ldsi*)s_tr);
         m4_mul_lds16(LDSD(s_se3), LDSD(s_E), LDSD(s_cand), lane);     // se3 * Exp(-x): used only if the step is accepted
         m4_mul_lds16(LDSD(s_cand), LDSD(s_last), LDSD(s_posec), lane);   // ... and the trial pose that goes with it
       }
