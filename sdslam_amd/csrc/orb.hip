@@ -703,7 +703,9 @@ __device__ unsigned long long g_sel_prof[64];
 #endif
 
 #define SEL_WAVES 8
-#define SEL_CELL_CAP 1024   // candidates of one cell staged per wave (LDS)
+#ifndef SEL_CELL_CAP
+#define SEL_CELL_CAP 512    // candidates of one cell staged per wave (LDS); larger cells: wave 0 with all the waves' buffers
+#endif
 #define SEL_LIST_CAP 1536   // level list (LDS)
 #define SEL_MAX_CELLS 512
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -810,6 +812,28 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void k_select_level(const OrbPlan* 
           for (int i = lane; i < keep; i += 64) glist[o + i] = buf[i];
         }
         sdsel::wave_fence();   // buf is reused by this wave's next cell
+      }
+    }
+  }
+  __syncthreads();
+  // cells with more candidates than one wave's buffer (dense texture, large cells of big frames): wave 0, one cell at a
+  // time, with the buffers of all waves as one (SEL_WAVES x SEL_CELL_CAP entries); beyond that the serial replay in HBM
+  if (wave == 0) {
+    lds_u32* big = (lds_u32*)s_buf[0];
+    for (int c = 0; c < nC; c++) {
+      const int n = s_total[c], keep = min(n, s_retain[c]), o = s_off[c];
+      if (keep <= 0 || n <= SEL_CELL_CAP) continue;
+      uint32_t* src = gcand + cg[c].cand_off;
+      if (n <= SEL_WAVES * SEL_CELL_CAP) {
+        for (int i = lane; i < n; i += 64) big[i] = src[i];
+        sdsel::wave_fence();
+        if (n > keep) sdsel::wave_nth_element(big, n, keep, (sdsel::lds_u16*)s_tmp[0]);
+        if (list_lds) {
+          for (int i = lane; i < keep; i += 64) s_list[o + i] = big[i];
+        } else {
+          for (int i = lane; i < keep; i += 64) glist[o + i] = big[i];
+        }
+        sdsel::wave_fence();
       } else {
         if (lane == 0) {
           if (n > keep) sdsel::nth_element(src, n, keep);
