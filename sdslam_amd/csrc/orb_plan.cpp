@@ -195,7 +195,7 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
               size_t tp = up((size_t)c.zw + 6 + 3, 4), sp = up((size_t)c.zw + 2, 4);
               size_t rpw = (size_t)(S + 2 + 3) / 4;
               size_t need = tp * (S + 2 + 6) + sp * (S + 2 + 2) + 2 * 4 * rpw * c.zw + 64;
-              static const size_t lds_kb = [] { const char* e = getenv("SD_FAST_LDS_KB"); return e ? (size_t)atoi(e) : (size_t)20; }();   // experiments
+              static const size_t lds_kb = [] { const char* e = getenv("SD_FAST_LDS_KB"); return e ? (size_t)atoi(e) : (size_t)24; }();   // experiments; 24 KB measured best at 8 waves per SIMD (r2)
               bool fits = need <= lds_kb * 1024 && rpw * c.zw <= 4096 && (size_t)(S + 2) * c.zw < 65536;
               if (fits || S == 1) { lds_max = std::max(lds_max, need); break; }
               S = std::max(1, S - std::max(1, S / 8));
