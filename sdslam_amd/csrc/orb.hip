@@ -705,9 +705,9 @@ __device__ unsigned long long g_sel_prof[64];
 #endif
 
 #define SEL_WAVES 8
-#ifndef SEL_CELL_CAP
-#define SEL_CELL_CAP 512    // candidates of one cell staged per wave (LDS); larger cells: wave 0 with all the waves' buffers
-#endif
+// candidates of one cell staged per wave (dynamic LDS, chosen per geometry by select_cell_cap()): 512 keeps four workgroups
+// per CU on VGA-sized cells; frames with large cells (1280x720: 311 x 98 pixels) take 1024.  Larger cells: wave 0 with all the
+// waves' buffers as one
 #define SEL_LIST_CAP 1536   // level list (LDS)
 #define SEL_MAX_CELLS 512
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -719,8 +719,8 @@ __global__ __launch_bounds__(64 * SEL_WAVES, 8) void k_select_level(const OrbPla
                                                                 const int32_t* __restrict__ cell_count,
                                                                 uint32_t* __restrict__ lvl_scratch,
                                                                 uint32_t* __restrict__ sel,
-                                                                int32_t* __restrict__ sel_count) {
-  __shared__ uint32_t s_buf[SEL_WAVES][SEL_CELL_CAP];
+                                                                int32_t* __restrict__ sel_count, int SEL_CELL_CAP) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_buf_dyn[];   // [SEL_WAVES][SEL_CELL_CAP]
   __shared__ uint32_t s_list[SEL_LIST_CAP];
   __shared__ uint16_t s_tmp[SEL_WAVES][2 * WAVE_SEL_CAP];   // stop tables of the wave-parallel partition
   __shared__ int s_total[SEL_MAX_CELLS];
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES, 8) void k_select_level(const OrbPla
   uint32_t* glist = lvl_scratch + (size_t)frame * P->cand_per_frame + L.cand_off;
   // ---- per-cell retainBest, one wave per cell
   {
-    lds_u32* buf = (lds_u32*)s_buf[wave];
+    lds_u32* buf = (lds_u32*)(s_buf_dyn + (size_t)wave * SEL_CELL_CAP);
     for (int c = wave; c < nC; c += SEL_WAVES) {
       const int n = s_total[c], keep = min(n, s_retain[c]), o = s_off[c];
       if (keep <= 0) continue;
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES, 8) void k_select_level(const OrbPla
   // cells with more candidates than one wave's buffer (dense texture, large cells of big frames): wave 0, one cell at a
   // time, with the buffers of all waves as one (SEL_WAVES x SEL_CELL_CAP entries); beyond that the serial replay in HBM
   if (wave == 0) {
-    lds_u32* big = (lds_u32*)s_buf[0];
+    lds_u32* big = (lds_u32*)s_buf_dyn;
     for (int c = 0; c < nC; c++) {
       const int n = s_total[c], keep = min(n, s_retain[c]), o = s_off[c];
       if (keep <= 0 || n <= SEL_CELL_CAP) continue;
@@ -1314,8 +1314,9 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   SD_HIP_CHECK(hipEventRecord(h->ev_fast_done, h->fast_stream));
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_fast_done, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[9], s));
-  hipLaunchKernelGGL(k_select_level, dim3(P.nlevels, n), dim3(64 * SEL_WAVES), 0, s, h->d_plan, h->d_cells, h->d_cand,
-                     h->d_cell_count, h->d_scratch, h->d_sel, h->d_sel_count);
+  const int sel_cap = hp.max_cell_pixels > 12000 ? 1024 : 512;
+  hipLaunchKernelGGL(k_select_level, dim3(P.nlevels, n), dim3(64 * SEL_WAVES), (size_t)SEL_WAVES * sel_cap * 4, s, h->d_plan, h->d_cells, h->d_cand,
+                     h->d_cell_count, h->d_scratch, h->d_sel, h->d_sel_count, sel_cap);
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[7], s));
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_blur_done, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[4], s));

@@ -78,6 +78,7 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
   hp.blur_tiles.clear();
   hp.coef.clear();
   hp.max_cells_per_level = 0;
+  hp.max_cell_pixels = 0;
 
   size_t off = 0;
   uint32_t cand = 0;
@@ -187,6 +188,7 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
           c.cand_off = cand;
           cand += c.cap;
           c.strip_rows = 0;
+          if (ok) hp.max_cell_pixels = std::max(hp.max_cell_pixels, c.zw * c.zh);
           if (ok) {
             // strip height: <= 64 queue chunks per wave (bits in a u64), <= 2^16 queue indices,
             // LDS = pixel tile + score map + per-wave u16 queues (worst case one entry per pixel)
