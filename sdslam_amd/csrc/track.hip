@@ -223,13 +223,16 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
     for (int r = 0; r < sd_track::kRing && e == hipSuccess; r++)
       for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&h->ev[r][i]);
     if (e == hipSuccess) {
-      // lowest priority: the tracking workgroups are few, long-running and latency-bound; they fill the slots the
-      // extraction kernels of the next batch leave free instead of taking slots from them.  Measured (full step with PnP,
-      // 1024 frames): low 122.3 k, normal 119.9 k, high 119.2 k frames/s; no difference for a single frame.
+      // Priority of the tracking stream.  Round 1 (extraction kernels at 6-7 waves per SIMD): lowest was best (122.3 k vs
+      // 119.2 k frames/s at highest) -- the few, long-running, latency-bound tracking workgroups filled what the extraction
+      // left free.  Round 2 (FAST / select at 8 waves per SIMD leave nothing free): the chain of tracking kernels starves at
+      // the lowest priority and becomes the longest path of the step when it is long (TrackWithMotionModel + TrackLocalMap:
+      // low 107.3 k, normal 108.3 k, HIGH 113.3 k frames/s); with the PnP step all three are within 0.5 % (145.7 / 145.4 /
+      // 146.1 k).  Default: highest.
       int lo = 0, hi = 0;
       e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-      const char* pe = getenv("SD_TRACK_PRIO");   // experiments: "high" | "normal" | default low
-      const int prio = (pe && pe[0] == 'h') ? hi : ((pe && pe[0] == 'n') ? (lo + hi) / 2 : lo);
+      const char* pe = getenv("SD_TRACK_PRIO");   // experiments: "low" | "normal" | default high
+      const int prio = (pe && pe[0] == 'l') ? lo : ((pe && pe[0] == 'n') ? (lo + hi) / 2 : hi);
       if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->pnp_stream, hipStreamNonBlocking, prio);
     }
     if (e != hipSuccess) {
