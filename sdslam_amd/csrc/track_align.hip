@@ -269,9 +269,9 @@ __global__ __launch_bounds__(AL_PT_THREADS, MINW) void k_align(const OrbPlan* __
   __shared__ int s_ctrl[4];   // [0] break flag, [2] level-loop exit
   __shared__ int s_iters[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // persistent workgroups: the grid may be smaller than the batch (launch_align)
-  for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
-  __syncthreads();   // shared state of the previous frame is dead
+  const int f = blockIdx.x;   // one workgroup per frame pair
+  if (f >= n_frames) return;
+  {
   const int M = tb.max_points;
   const uint8_t* valid = tb.valid + (size_t)f * M;
   const double* Xw = tb.Xw + (size_t)f * M * 3;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(AL_PT_THREADS, MINW) void k_align(const OrbPlan* __
       tb.al_chi2[f] = 1e10;
       for (int l = 0; l < 16; l++) tb.al_iters[(size_t)f * 16 + l] = 0;
     }
-    continue;
+    return;
   }
   if (tid == 0) {
     // column-major in HBM (Eigen::Matrix4d::data()) -> row-major working copies (s_E: the prior, s_cand: the inverse)
@@ -501,6 +501,10 @@ __global__ __launch_bounds__(AL_PT_THREADS, MINW) void k_align(const OrbPlan* __
 #pragma unroll
               for (int px = 0; px < 4; px++) {
                 float pv, fdx, fdy;
+                // (opaque to the optimiser per pixel: sharing the byte -> float conversions of the 4 x 7 window rows between
+                // the pixels of a patch row keeps 28 more floats alive than the 96-VGPR budget has room for)
+                asm volatile("" : "+v"(rlo[py]), "+v"(rhi[py]), "+v"(rlo[py + 1]), "+v"(rhi[py + 1]), "+v"(rlo[py + 2]), "+v"(rhi[py + 2]),
+                             "+v"(rlo[py + 3]), "+v"(rhi[py + 3]));
                 REF_PIXEL(px, py, pv, fdx, fdy);
                 const float intensity = w_tl * CPX(py, px) + w_tr * CPX(py, px + 1) + w_bl * CPX(py + 1, px) + w_br * CPX(py + 1, px + 1);
                 const float res = intensity - pv;
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(AL_PT_THREADS, MINW) void k_align(const OrbPlan* __
     tb.al_chi2[f] = chi2_;
     NOUNROLL for (int l = 0; l < 16; l++) tb.al_iters[(size_t)f * 16 + l] = s_iters[l];
   }
-  }   // frames of this workgroup
+  }
 }
 
 int read_align_prof(unsigned long long* out16, int reset) {
@@ -692,8 +696,7 @@ int read_align_prof(unsigned long long* out16, int reset) {
 
 int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sf,
                  const float* d_sf, int n_frames, int mode, hipStream_t s) {
-  static const int grid_cap = [] { const char* e = getenv("SD_ALIGN_GRID"); return e ? atoi(e) : 0; }();
-  const int grid = grid_cap > 0 ? std::min(n_frames, grid_cap) : n_frames;
+  const int grid = n_frames;
   // register budget: 5 waves per SIMD = four workgroups per CU (1024 frames resident at once); SD_ALIGN_MINW=3|4 for experiments
   static const int minw = [] { const char* e = getenv("SD_ALIGN_MINW"); return e ? atoi(e) : AL_DEFAULT_MINW; }();
   if (minw == 3)
