@@ -342,6 +342,7 @@ class FrameTracker {
   template <class FrameT>
   int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, float th, bool bMono, bool checkOrientation = true) {
     Upload(CurrentFrame, LastFrame);
+    if (!bMono) UploadURight(CurrentFrame, 0);   // RGB-D / stereo: the mvuRight gate of src/ORBmatcher.cc:1020-1025
     check(sd_track_match(batch_.handle(), 1, th, bMono ? 1 : 0, checkOrientation ? 1 : 0));
     std::vector<int32_t> idx(CurrentFrame.N > 0 ? cap(CurrentFrame) : 1);
     int32_t n = 0;
@@ -373,6 +374,7 @@ class FrameTracker {
     const auto Tc = F.GetPose();
     check(sd_track_set_poses(batch_.handle(), 0, 1, Tc.data(), Tc.data()));
     check(sd_track_set_matches(batch_.handle(), 0, 1, cm.data(), F.N));
+    UploadURight(F, 0);                        // stereo edges where mvuRight >= 0 (src/Optimizer.cc:262-300)
     check(sd_track_pose_opt(batch_.handle(), 1, 0));
     std::vector<uint8_t> outl(cap(F));
     double T[16];
@@ -387,6 +389,13 @@ class FrameTracker {
  private:
   template <class FrameT>
   int cap(const FrameT& F) { return F.N > max_points_ ? F.N : max_points_; }
+  // CurrentFrame.mvuRight (filled by Frame::ComputeStereoFromRGBD / ComputeStereoMatches in the reference's constructor)
+  template <class FrameT>
+  auto UploadURight(const FrameT& F, int) -> decltype((void)F.mvuRight) {
+    if (!F.mvuRight.empty()) batch_.SetURight(0, F.mvuRight.data(), (int)F.mvuRight.size());
+  }
+  template <class FrameT>
+  void UploadURight(const FrameT&, long) {}   // frame types without mvuRight (monocular builds)
   template <class FrameT>
   void SetCameraOf(const FrameT& F) {
     batch_.SetCamera(FrameT::fx, FrameT::fy, FrameT::cx, FrameT::cy, F.mbf, FrameT::mnMinX, FrameT::mnMaxX, FrameT::mnMinY, FrameT::mnMaxY);

@@ -39,6 +39,9 @@ SCENARIOS = {
     "minset5": (dict(n_match=250, outlier_frac=0.30, noise_px=0.5), (0.99, 10, 100, 5, 0.28, 5.991), [100, 3]),
     "minset6_out50": (dict(n_match=250, outlier_frac=0.50, noise_px=0.5), (0.99, 10, 100, 6, 0.3, 5.991), [100]),
     "minset8": (dict(n_match=200, outlier_frac=0.20, noise_px=0.3), (0.99, 10, 60, 8, 0.4, 5.991), [60]),
+    # fewer points than EPnP's four control points: the covariance of the set is rank deficient, no hypothesis reaches
+    # minInliers in either implementation (empty Mat + bNoMore); pins that degenerate sets are handled, not that they work
+    "minset3_degenerate": (dict(n_match=250, outlier_frac=0.30, noise_px=0.5), (0.99, 10, 60, 3, 0.28, 5.991), [60]),
 }
 
 
