@@ -19,3 +19,8 @@ print("pnp alone ms", t(lambda: trk.pnp(1024, 0.99, 10, 200, 4, 0.28, 5.991, 200
 print("step ms", t(wl.step, 40))
 al = trk.get_align(0, 1024)
 print("gn iters", al["iters"][:, :8].sum(axis=1).mean(), "ok", al["ok"].sum())
+ones = np.ones((1024, wl.cur.cap), np.uint8)
+trk.set_point_flags(0, ones, ones)
+print("search_by_points (1000 x 1000 brute force) alone ms", t(lambda: trk.search_by_points(1024, 0.75, True)))
+m12, n12 = trk.get_point_matches(0, 1024)
+print("mean point matches", n12.mean())
