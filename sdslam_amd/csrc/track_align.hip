@@ -574,12 +574,15 @@ __global__ __launch_bounds__(AL_PT_THREADS, MINW) void k_align(const OrbPlan* __
         for (int c0 = 0; c0 < n4; c0 += 64) {
           const int idx = c0 + lane;
           const float4 v = idx < n4 ? c4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-          float d = 0.0f;
+          // one step = four dependent adds: u = d[l-1] + x as ONE v_add_f32 with a DPP source (wave_shr:1); lane 0 has no left
+          // neighbour, so the instruction leaves its u alone -- preset to carry + x[0], lane 0's first partial sum in every step.
+          // (As v_mov_b32_dpp + v_add_f32 with the carry as the DPP `old` operand the compiler needed seven issue slots per
+          // step.)  s_nop 1: the two wait states between the VALU write of d and its DPP read.
+          float d = 0.0f, u = chi2f + v.x;
 #pragma unroll 8
           for (int st = 0; st < 64; st++) {
-            const float in = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(chi2f), __float_as_int(d), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-            d = in + v.x;
-            d = d + v.y;
+            asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(u) : "v"(d), "v"(v.x));
+            d = u + v.y;
             d = d + v.z;
             d = d + v.w;
           }
