@@ -371,7 +371,7 @@ __device__ __noinline__ void jacobi_sweeps12_coop(Ptr A, Ptr W, int g, bool act,
 }
 
 // cvSVD of a row-major 3 x 3 matrix: Ut rows = left vectors, Vt rows = right vectors
-__device__ __noinline__ void svd3(const double* A, double* W, double* Ut, double* Vt) {
+__device__ __forceinline__ void svd3(const double* A, double* W, double* Ut, double* Vt) {
   double at[3][3], w[3], vt[3][3];
 #pragma unroll
   for (int i = 0; i < 3; i++)
