@@ -879,7 +879,10 @@ __global__ __launch_bounds__(64 * SEL_WAVES, 8) void k_select_level(const OrbPla
 // saturated.  The padded pyramid already holds the REFLECT_101 border, so no border logic.
 // Register sliding window, no LDS: a thread owns 4 adjacent output columns of a 32-row band,
 // reads each input row as 3 aligned dwords (12 bytes cover the 4+6 taps), keeps the last 7
-// row-pass results in registers and emits one packed 4-byte store per row.  Only levels that
+// row-pass results in registers (as pairs of vertically adjacent rows) and emits one packed 4-byte
+// store per row.  The taps run on the integer dot-product instructions (v_dot4_u32_u8 for the
+// row pass over bytes, v_dot2_u32_u16 for the column pass over the 16-bit row results): 997
+// vector instructions per 128 outputs instead of 1570 with mul24 / mad chains, same integers.  Only levels that
 // own keypoints are blurred by the reference (src/ORBextractor.cc:655-660); here every level is
 // (the blurred image is not an output), which frees the stage from waiting for the selection.
 // ------------------------------------------------------------------------------------------
@@ -903,33 +906,44 @@ __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, con
   uint8_t* dst = blur + fo + (size_t)(y0 + SD_EDGE) * L.pstride + (x0 + SD_EDGE);
   const int nrows = min(BLUR_RB, L.h - y0);
   const bool full = x0 + 3 < L.w;
-  int ring[7][4];
+  // Row pass: out[k] = sum_i tap[i] * byte[k + i] as two v_dot4_u32_u8 over byte windows cut out of the three dwords with
+  // v_alignbyte (<= 255 * 257 = 65535: fits 16 bits).  Column pass: vertically adjacent row results packed in pairs
+  // P[r] = R[r] | R[r+1] << 16, so an output is three v_dot2_u32_u16 and one mad; (s + 2^15) >> 16 and the saturation to 255
+  // are one v_perm (high halves of two sums) + v_sat_pk_u8_i16 per pixel pair.
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const uint32_t T0 = 18u | 34u << 8 | 49u << 16 | 55u << 24, T1 = 49u | 34u << 8 | 18u << 16;
+  const us2 T01 = {18, 34}, T23 = {49, 55}, T45 = {49, 34};
+  uint32_t PP[6][4], prevR[4];
 #pragma unroll
   for (int r = 0; r < BLUR_RB + 6; r++) {
     if (r < nrows + 6) {
       const uint32_t* rp = (const uint32_t*)(src + (size_t)r * L.pstride);
       const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2];
-      int b[12];
+      uint32_t R[4];
+      R[0] = __builtin_amdgcn_udot4(w0, T0, __builtin_amdgcn_udot4(w1, T1, 0u, false), false);
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        b[k] = (w0 >> (8 * k)) & 0xff;
-        b[4 + k] = (w1 >> (8 * k)) & 0xff;
-        b[8 + k] = (w2 >> (8 * k)) & 0xff;
+      for (int k = 1; k < 4; k++)
+        R[k] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, k), T0,
+                                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, k), T1, 0u, false), false);
+      if (r >= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) PP[(r - 1) % 6][k] = prevR[k] | (R[k] << 16);
       }
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        ring[r % 7][k] = __mul24(18, b[k] + b[k + 6]) + __mul24(34, b[k + 1] + b[k + 5]) + __mul24(49, b[k + 2] + b[k + 4]) + __mul24(55, b[k + 3]);
       if (r >= 6) {
-        // output row r-6 uses row-pass results of input rows r-6 .. r (ring slots (r-6+i) % 7)
-        uint32_t packed = 0;
+        // output row r-6 = taps over row results r-6 .. r = PP[r-6], PP[r-4], PP[r-2] and R[r]
+        uint32_t sum[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          int s = __mul24(18, ring[(r - 6) % 7][k] + ring[r % 7][k]) + __mul24(34, ring[(r - 5) % 7][k] + ring[(r - 1) % 7][k]) +
-                  __mul24(49, ring[(r - 4) % 7][k] + ring[(r - 2) % 7][k]) + __mul24(55, ring[(r - 3) % 7][k]);
-          int v = (s + (1 << 15)) >> 16;
-          v = v > 255 ? 255 : v;
-          packed |= (uint32_t)v << (8 * k);
+          uint32_t a = (uint32_t)__mul24(18, (int)R[k]) + (1u << 15);
+          a = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, PP[(r - 2) % 6][k]), T45, a, false);
+          a = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, PP[(r - 4) % 6][k]), T23, a, false);
+          sum[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, PP[(r - 6) % 6][k]), T01, a, false);
         }
+        uint32_t h01 = __builtin_amdgcn_perm(sum[1], sum[0], 0x07060302u), h23 = __builtin_amdgcn_perm(sum[3], sum[2], 0x07060302u);
+        uint32_t p01, p23;
+        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p01) : "v"(h01));   // values 0..257 as i16 -> u8, saturated
+        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p23) : "v"(h23));
+        const uint32_t packed = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
         uint8_t* o = dst + (size_t)(r - 6) * L.pstride;
         if (full) {
           __builtin_memcpy(o, &packed, 4);   // interior starts at padded column 19: 4-byte store, 1-byte aligned
@@ -938,6 +952,8 @@ __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, con
             if (x0 + k < L.w) o[k] = (uint8_t)(packed >> (8 * k));
         }
       }
+#pragma unroll
+      for (int k = 0; k < 4; k++) prevR[k] = R[k];
     }
   }
 }
