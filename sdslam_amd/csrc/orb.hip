@@ -524,7 +524,8 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const OrbPlan* __restrict
                                                     const CellGeom* __restrict__ cells,
                                                     const uint8_t* __restrict__ pyr,
                                                     uint32_t* __restrict__ cand,
-                                                    int32_t* __restrict__ cell_count, int cell0) {
+                                                    int32_t* __restrict__ cell_count, int cell0,
+                                                    const uint8_t* __restrict__ src0, int src_stride, size_t src_frame_stride) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int wcnt[4];
   const int cell = blockIdx.x + cell0;   // launched per level: the cells of a level are contiguous
@@ -536,11 +537,14 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const OrbPlan* __restrict
     return;
   }
   const LevelGeom L = P->lv[C.level];
-  const uint8_t* img = pyr + (size_t)frame * P->pyr_frame_bytes + L.off;
+  // Level 0 can be read straight from the caller's frames (src0 != NULL; 4-byte aligned base / strides): FAST only touches
+  // interior pixels (the zones start SD_EDGE - 3 px inside), so it need not wait for the padded copy of the frame.
+  const uint8_t* img = src0 ? src0 + (size_t)frame * src_frame_stride : pyr + (size_t)frame * P->pyr_frame_bytes + L.off;
+  const int pstride = src0 ? src_stride : L.pstride, edge = src0 ? 0 : SD_EDGE;
   uint32_t* out = cand + (size_t)frame * P->cand_per_frame + C.cand_off;
   const int th = P->thFAST;
   const int zw = C.zw, zh = C.zh, S = C.strip_rows;
-  const int xs = C.zx0 - 3 + SD_EDGE;   // padded x of tile column 0 (before alignment)
+  const int xs = C.zx0 - 3 + edge;   // x of tile column 0 in the source rows (before alignment)
   const int xa = xs & ~3, sh = xs - xa;
   const int TPW = (sh + zw + 6 + 3) >> 2;   // tile pitch in 4-byte words
   const int TP = TPW * 4;
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const OrbPlan* __restrict
     const int npr = nsr + 6;
     // ---- stage pixels (aligned words) and clear the score map
     {
-      const uint8_t* g = img + (size_t)(C.zy0 + sr0 - 3 + SD_EDGE) * L.pstride + xa;
+      const uint8_t* g = img + (size_t)(C.zy0 + sr0 - 3 + edge) * pstride + xa;
       // loads are issued 8 rows at a time before the first LDS store: one global round trip per batch
       for (int wc = lane; wc < TPW; wc += 64)
         for (int row0 = wave; row0 < npr; row0 += 32) {
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const OrbPlan* __restrict
 #pragma unroll
           for (int j = 0; j < 8; j++) {
             const int row = row0 + 4 * j;
-            v[j] = row < npr ? *(const uint32_t*)(g + (size_t)__mul24(row, L.pstride) + wc * 4) : 0u;
+            v[j] = row < npr ? *(const uint32_t*)(g + (size_t)__mul24(row, pstride) + wc * 4) : 0u;
           }
 #pragma unroll
           for (int j = 0; j < 8; j++) {
@@ -1014,7 +1018,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
   const int lane = threadIdx.x & 63;
   // Two keypoints per wave, interleaved: the kernel is a chain of dependent gathers (key -> 31 x 31 patch -> angle ->
   // 512 sample points), so a wave with two independent chains in flight keeps twice the loads outstanding.
-  const int g0 = (blk * 4 + (threadIdx.x >> 6)) * DESC_KPW;   // output slots g0 .. g0 + DESC_KPW - 1
+  // Everything that is the same for the whole wave (keypoint position, level geometry, patch base pointers, angle, cos, sin) is
+  // made scalar with readfirstlane / readlane: the gathers then use the SGPR-base + 32-bit-offset addressing form (no 64-bit
+  // vector address arithmetic), and the angle / cos / sin of BOTH keypoints are evaluated once, in the two halves of the wave.
+  const int g0 = __builtin_amdgcn_readfirstlane((blk * 4 + (int)(threadIdx.x >> 6)) * DESC_KPW);   // output slots g0 .. g0 + DESC_KPW - 1
   const int32_t* sc = sel_count + (size_t)frame * P->nlevels;
   int level[DESC_KPW], idx[DESC_KPW], acc = 0;
 #pragma unroll
@@ -1032,8 +1039,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
   if (blk == 0 && threadIdx.x == 0) nout[frame] = min(acc, cap);
   bool live[DESC_KPW];
   int X[DESC_KPW], Y[DESC_KPW], resp[DESC_KPW], step[DESC_KPW];
-  const uint8_t* center[DESC_KPW];
-  const uint8_t* bc[DESC_KPW];
+  const uint8_t* pbase[DESC_KPW];   // pixel (X - 19, Y - 19) of the level: every offset below is non-negative (the border is 19 px)
+  const uint8_t* bbase[DESC_KPW];   // same position in the blurred level
   float scale[DESC_KPW], kpsize[DESC_KPW];
 #pragma unroll
   for (int q = 0; q < DESC_KPW; q++) {
@@ -1047,49 +1054,69 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
     step[q] = L.pstride;
     scale[q] = L.scale;
     kpsize[q] = L.kpsize;
-    const size_t fo = (size_t)frame * P->pyr_frame_bytes + L.off + (size_t)(Y[q] + SD_EDGE) * L.pstride + X[q] + SD_EDGE;
-    center[q] = pyr + fo;
-    bc[q] = blur + fo;
+    const size_t fo = (size_t)frame * P->pyr_frame_bytes + L.off + (size_t)(Y[q] + SD_EDGE - 19) * L.pstride + X[q] + SD_EDGE - 19;
+    pbase[q] = pyr + fo;
+    bbase[q] = blur + fo;
   }
   if (!live[0]) return;   // slots are filled in order: no first keypoint, no second
 
-  // ---- IC_Angle
+  // ---- IC_Angle: m10 = sum u * I, m01 = sum v * I over the disc.  Lane = (column u, half): the lower half of the wave walks
+  // the rows +v, the upper half the rows -v; per row one load per keypoint, u * (sum of the column) and +-(sum of v * I) at
+  // the end (integer sums: any order is exact).
   int m10[DESC_KPW], m01[DESC_KPW];
-#pragma unroll
-  for (int q = 0; q < DESC_KPW; q++) m10[q] = m01[q] = 0;
   {
     const int u = (lane & 31) - 15;
     const int half = lane >> 5;   // 0: rows +v, 1: rows -v
     const bool act = (lane & 31) < 31;
     const int au = abs(u);
+    uint32_t off[DESC_KPW];
+    int dstep[DESC_KPW], colsum[DESC_KPW], vsum[DESC_KPW];
+#pragma unroll
+    for (int q = 0; q < DESC_KPW; q++) {
+      off[q] = (uint32_t)(19 * step[q] + 19 + u);
+      dstep[q] = half ? -step[q] : step[q];
+      colsum[q] = vsum[q] = 0;
+    }
 #pragma unroll
     for (int v = 0; v <= 15; v++) {   // fully unrolled: the 2 x 16 row loads are independent and issue back to back
       if (act && au <= c_umax[v] && !(half && v == 0)) {
 #pragma unroll
         for (int q = 0; q < DESC_KPW; q++) {
-          const int val = center[q][u + v * (half ? -step[q] : step[q])];
-          m10[q] += u * val;
-          m01[q] += (half ? -v : v) * val;
+          const int val = pbase[q][off[q]];
+          colsum[q] += val;
+          vsum[q] += v * val;
         }
       }
+#pragma unroll
+      for (int q = 0; q < DESC_KPW; q++) off[q] += (uint32_t)dstep[q];
     }
 #pragma unroll
-    for (int q = 0; q < DESC_KPW; q++) {   // integer sums: any order is exact; DPP reduction of the device library
-      m10[q] = __ockl_wfred_add_i32(m10[q]);
-      m01[q] = __ockl_wfred_add_i32(m01[q]);
+    for (int q = 0; q < DESC_KPW; q++) {   // DPP reduction of the device library
+      m10[q] = __ockl_wfred_add_i32(u * colsum[q]);
+      m01[q] = __ockl_wfred_add_i32(half ? -vsum[q] : vsum[q]);
+    }
+  }
+  // ---- angle, cos, sin: keypoint 0 in lanes 0..31, keypoint 1 in lanes 32..63, one evaluation
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  float angle[DESC_KPW], ca[DESC_KPW], sb[DESC_KPW];
+  {
+    static_assert(DESC_KPW == 2, "the angle evaluation splits the wave in two");
+    const float my = (float)(lane < 32 ? m01[0] : m01[1]), mx = (float)(lane < 32 ? m10[0] : m10[1]);
+    const float ang = fast_atan2_deg(my, mx);
+    const float arad = ang * factorPI;
+    const float c = sdsc::cosf_glibc(arad), sn = sdsc::sinf_glibc(arad);
+#pragma unroll
+    for (int q = 0; q < DESC_KPW; q++) {
+      angle[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang), 32 * q));
+      ca[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 32 * q));
+      sb[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sn), 32 * q));
     }
   }
   // ---- steered rBRIEF on the blurred level
-  const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  float angle[DESC_KPW], ca[DESC_KPW], sb[DESC_KPW];
-#pragma unroll
-  for (int q = 0; q < DESC_KPW; q++) {
-    angle[q] = fast_atan2_deg((float)m01[q], (float)m10[q]);
-    const float arad = angle[q] * factorPI;
-    ca[q] = sdsc::cosf_glibc(arad);
-    sb[q] = sdsc::sinf_glibc(arad);
-  }
   unsigned long long words[DESC_KPW][4];
+  int c19[DESC_KPW];
+#pragma unroll
+  for (int q = 0; q < DESC_KPW; q++) c19[q] = 19 * step[q] + 19;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int t = j * 64 + lane;
@@ -1102,8 +1129,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
       // center[cvRound(x*b + y*a)*step + cvRound(x*a - y*b)]
       const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
       const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
-      t0[q] = bc[q][__mul24(r0, step[q]) + q0];
-      t1[q] = bc[q][__mul24(r1, step[q]) + q1];
+      t0[q] = bbase[q][(uint32_t)(__mul24(r0, step[q]) + q0 + c19[q])];
+      t1[q] = bbase[q][(uint32_t)(__mul24(r1, step[q]) + q1 + c19[q])];
     }
 #pragma unroll
     for (int q = 0; q < DESC_KPW; q++) words[q][j] = __ballot(t0[q] < t1[q]);
@@ -1284,6 +1311,14 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   SD_HIP_CHECK(hipEventRecord(h->ev_fast_done, s));
   SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_fast_done, 0));
   const bool src_aligned = (((uintptr_t)d_imgs | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) == 0;
+  // FAST of level 0 reads the frames themselves when they are 4-byte aligned: it starts at once, beside the resize chain
+  const bool fast0_direct = src_aligned && P.lv[0].ncells > 0 && getenv("SD_FAST0_PYR") == nullptr;
+  if (fast0_direct) {
+    if (prof) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
+    fast_started = true;
+    hipLaunchKernelGGL(k_fast_cells, dim3(P.lv[0].ncells, n), dim3(256), hp.fast_lds_bytes, h->fast_stream, h->d_plan, h->d_cells,
+                       h->d_pyr, h->d_cand, h->d_cell_count, P.lv[0].cell0, d_imgs, stride, frame_stride);
+  }
   for (int l = 0; l < P.nlevels; l++) {
     const LevelGeom& L = P.lv[l];
     const LevelGeom& S = P.lv[l > 0 ? l - 1 : 0];
@@ -1305,13 +1340,13 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
                        h->d_pyr, wpr, magic((unsigned)wpr));
     }
     // FAST of this level starts now, on its own stream
-    if (L.ncells > 0) {
+    if (L.ncells > 0 && !(l == 0 && fast0_direct)) {
       SD_HIP_CHECK(hipEventRecord(h->ev_level[l], s));
       SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_level[l], 0));
       if (prof && !fast_started) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
       fast_started = true;
       hipLaunchKernelGGL(k_fast_cells, dim3(L.ncells, n), dim3(256), hp.fast_lds_bytes, h->fast_stream, h->d_plan, h->d_cells,
-                         h->d_pyr, h->d_cand, h->d_cell_count, L.cell0);
+                         h->d_pyr, h->d_cand, h->d_cell_count, L.cell0, (const uint8_t*)nullptr, 0, (size_t)0);
     }
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], s));

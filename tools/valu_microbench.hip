@@ -23,10 +23,13 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 enum { OP_MAX3 = 0, OP_MIN3, OP_PERM, OP_MUL24, OP_MAD24, OP_CMP_SOR, OP_PKMAX16, OP_PKMIN16, OP_ADD, OP_BCNT, OP_ALIGNBYTE, OP_ANDOR, OP_LSHLADD,
-       OP_CNDMASK, OP_SUBREV, OP_DS_READ_U8, OP_DS_READ_B32, OP_COUNT };
+       OP_CNDMASK, OP_SUBREV, OP_DS_READ_U8, OP_DS_READ_B32,
+       OP_DOT4, OP_DOT2, OP_SATPK, OP_MULLO, OP_CMP, OP_AND, OP_LSHL, OP_BFE, OP_FMA32, OP_FMA64, OP_ADD64, OP_MUL64, OP_RCP32, OP_CVT, OP_COUNT };
 static const char* kNames[OP_COUNT] = {"v_max3_i32", "v_min3_i32", "v_perm_b32", "v_mul_i32_i24", "v_mad_i32_i24", "v_cmp_lt_i32+s_or_b64", "v_pk_max_u16",
                                        "v_pk_min_u16", "v_add_u32", "v_bcnt_u32_b32", "v_alignbyte_b32", "v_and_or_b32", "v_lshl_add_u32", "v_cndmask_b32",
-                                       "v_subrev_u32", "ds_read_u8", "ds_read_b32"};
+                                       "v_subrev_u32", "ds_read_u8", "ds_read_b32",
+                                       "v_dot4_u32_u8", "v_dot2_u32_u16", "v_sat_pk_u8_i16", "v_mul_lo_u32", "v_cmp_lt_i32 (vcc)", "v_and_b32", "v_lshlrev_b32",
+                                       "v_bfe_u32", "v_fma_f32", "v_fma_f64", "v_add_f64", "v_mul_f64", "v_rcp_f32", "v_cvt_f32_u32"};
 
 #define REP8(S)  S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 
@@ -45,6 +48,9 @@ __global__ __launch_bounds__(1024) void k_issue(unsigned long long* __restrict__
     for (int i = 0; i < 8; i++) a[i] = (t * 4 + i * 1024) & 16380;
   }
   unsigned long long sacc = 0;
+  double da[8], db = 1.0000001 + 1e-9 * (double)seed, dc = 1e-30 * (double)t;
+#pragma unroll
+  for (int i = 0; i < 8; i++) da[i] = 1.0 + 1e-6 * (double)(a[i] & 1023);
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -110,6 +116,62 @@ __global__ __launch_bounds__(1024) void k_issue(unsigned long long* __restrict__
 #define S(i) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
         REP8(S)
 #undef S
+      } else if (OP == OP_DOT4) {
+#define S(i) asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        REP8(S)
+#undef S
+      } else if (OP == OP_DOT2) {
+#define S(i) asm volatile("v_dot2_u32_u16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        REP8(S)
+#undef S
+      } else if (OP == OP_SATPK) {
+#define S(i) asm volatile("v_sat_pk_u8_i16 %0, %0" : "+v"(a[i]));
+        REP8(S)
+#undef S
+      } else if (OP == OP_MULLO) {
+#define S(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_CMP) {
+#define S(i) asm volatile("v_cmp_lt_i32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+        REP8(S)
+#undef S
+      } else if (OP == OP_AND) {
+#define S(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_LSHL) {
+#define S(i) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a[i]));
+        REP8(S)
+#undef S
+      } else if (OP == OP_BFE) {
+#define S(i) asm volatile("v_bfe_u32 %0, %0, 1, 31" : "+v"(a[i]));
+        REP8(S)
+#undef S
+      } else if (OP == OP_FMA32) {
+#define S(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        REP8(S)
+#undef S
+      } else if (OP == OP_FMA64) {
+#define S(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(da[i]) : "v"(db), "v"(dc));
+        REP8(S)
+#undef S
+      } else if (OP == OP_ADD64) {
+#define S(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(da[i]) : "v"(db));
+        REP8(S)
+#undef S
+      } else if (OP == OP_MUL64) {
+#define S(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(da[i]) : "v"(db));
+        REP8(S)
+#undef S
+      } else if (OP == OP_RCP32) {
+#define S(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+        REP8(S)
+#undef S
+      } else if (OP == OP_CVT) {
+#define S(i) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i]));
+        REP8(S)
+#undef S
       } else if (OP == OP_DS_READ_U8) {
         unsigned v[8];
 #define S(i) asm volatile("ds_read_u8 %0, %1" : "=v"(v[i]) : "v"(a[i]));
@@ -132,7 +194,7 @@ __global__ __launch_bounds__(1024) void k_issue(unsigned long long* __restrict__
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   unsigned s = c ^ (unsigned)sacc;
 #pragma unroll
-  for (int i = 0; i < 8; i++) s ^= a[i];
+  for (int i = 0; i < 8; i++) s ^= a[i] ^ (unsigned)__double2loint(da[i]);
   if ((t & 63) == 0) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -221,15 +283,17 @@ int main(int argc, char** argv) {
   if (!stream_only) {
     printf("{\"unit\": \"shader cycles per wave64 instruction per SIMD (median over all waves; W waves resident per SIMD)\",\n \"ops\": {\n");
     const int Ws[4] = {1, 2, 4, 8};
-    for (int op = 0; op < OP_COUNT; op++) {
+    const int op_first = (argc > 1 && !strcmp(argv[1], "--new")) ? (int)OP_DOT4 : 0;   // --new: only the r2e additions
+    for (int op = op_first; op < OP_COUNT; op++) {
       printf("  \"%s\": {", kNames[op]);
       for (int wi = 0; wi < 4; wi++) {
-        const int W = Ws[wi], iters = 16384;
+        const int W = Ws[wi], iters = (op == OP_MULLO || op >= OP_FMA64) ? 4096 : 16384;   // slow ops: shorter runs
         double r = 0, share = 0, wall = 0;
         switch (op) {
 #define C(O) case O: r = run_issue<O>(W, iters, d_out, h, &share, &wall); break;
           C(OP_MAX3) C(OP_MIN3) C(OP_PERM) C(OP_MUL24) C(OP_MAD24) C(OP_CMP_SOR) C(OP_PKMAX16) C(OP_PKMIN16) C(OP_ADD) C(OP_BCNT) C(OP_ALIGNBYTE)
-          C(OP_ANDOR) C(OP_LSHLADD) C(OP_CNDMASK) C(OP_SUBREV) C(OP_DS_READ_U8) C(OP_DS_READ_B32)
+          C(OP_ANDOR) C(OP_LSHLADD) C(OP_CNDMASK) C(OP_SUBREV) C(OP_DS_READ_U8) C(OP_DS_READ_B32) C(OP_DOT4) C(OP_DOT2) C(OP_SATPK) C(OP_MULLO)
+          C(OP_CMP) C(OP_AND) C(OP_LSHL) C(OP_BFE) C(OP_FMA32) C(OP_FMA64) C(OP_ADD64) C(OP_MUL64) C(OP_RCP32) C(OP_CVT)
 #undef C
         }
         printf("\"W%d\": %.3f, \"W%d_waves_sharing_simd\": %.2f, \"W%d_from_event_time_at_2.4GHz\": %.3f%s", W, r, W, share, W, wall, wi < 3 ? ", " : "");
