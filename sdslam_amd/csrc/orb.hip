@@ -974,7 +974,8 @@ __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, con
 __constant__ int8_t c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// umax[v] of the r = 15 disc (src/ORBextractor.cc:441-456); compile-time so that the unrolled row loop compares against literals
+static constexpr int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
@@ -1079,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
     }
 #pragma unroll
     for (int v = 0; v <= 15; v++) {   // fully unrolled: the 2 x 16 row loads are independent and issue back to back
-      if (act && au <= c_umax[v] && !(half && v == 0)) {
+      if (act && au <= kUmax[v] && !(half && v == 0)) {
 #pragma unroll
         for (int q = 0; q < DESC_KPW; q++) {
           const int val = pbase[q][off[q]];
