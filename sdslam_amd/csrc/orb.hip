@@ -267,7 +267,9 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const Lev
   if (Y0 >= (unsigned)Hh) return;
   const int g = (int)(e - Y0 * (unsigned)G);
   const int X0 = 1 + 4 * g;
-  uint8_t* dstb = pyr + (size_t)frame * pyr_frame_bytes + L.off + (size_t)SD_EDGE * L.pstride + (X0 + SD_EDGE);
+  // wave-uniform base pointers + 32-bit per-lane offsets: loads and stores use the SGPR-base addressing form
+  uint8_t* dstb = pyr + (size_t)frame * pyr_frame_bytes + L.off;
+  const uint32_t dst_x = (uint32_t)(SD_EDGE * L.pstride + X0 + SD_EDGE);
   uint32_t packed[PYR_RPT];
   bool live[PYR_RPT];
   int Yr[PYR_RPT];
@@ -280,10 +282,11 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const Lev
   if (level == 0) {
 #pragma unroll
     for (int r = 0; r < PYR_RPT; r++) {
-      const uint8_t* s = src0 + (size_t)frame * src_frame_stride + (size_t)Yr[r] * src_stride + X0;
-      const uintptr_t a = (uintptr_t)s;
-      const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
-      packed[r] = __builtin_amdgcn_alignbyte(q[1], q[0], (unsigned)(a & 3));
+      // k_pyr_resize runs for level 0 only when base pointer and strides are 4-byte aligned (pipeline_body)
+      const uint8_t* s = src0 + (size_t)frame * src_frame_stride;
+      const uint32_t o = (uint32_t)(__mul24(Yr[r], src_stride) + X0);
+      const uint32_t* q = (const uint32_t*)(s + (o & ~3u));
+      packed[r] = __builtin_amdgcn_alignbyte(q[1], q[0], o & 3u);
     }
   } else {
     const int32_t* xo = coef + L.cx;
@@ -294,33 +297,35 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const Lev
     uint32_t ab[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      sx[k] = xo[X0 + k];
-      ab[k] = (uint32_t)xa[X0 + k];
+      sx[k] = xo[(uint32_t)(X0 + k)];
+      ab[k] = (uint32_t)xa[(uint32_t)(X0 + k)];
     }
     const int base = sx[0];
-    uint32_t selA = 0, selB = 0;
+    // v_perm selector per output pixel: {left source byte, 0, right source byte, 0} of the row's 8-byte window = the two
+    // taps as a u16 pair, which v_dot2_u32_u16 multiplies with the packed coefficient pair ab[k] in one instruction
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    uint32_t selP[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int o = sx[k] - base;
       const int o1 = (sx[k] + 1 < S.w ? sx[k] + 1 : S.w - 1) - base;
-      selA |= (uint32_t)o << (8 * k);
-      selB |= (uint32_t)o1 << (8 * k);
+      selP[k] = (uint32_t)o | 0x0c00u | ((uint32_t)o1 << 16) | 0x0c000000u;
     }
-    const uint8_t* sb = pyr + (size_t)frame * pyr_frame_bytes + S.off + (size_t)SD_EDGE * S.pstride + SD_EDGE;
+    const uint8_t* sb = pyr + (size_t)frame * pyr_frame_bytes + S.off;   // 64-byte aligned (level offsets and row pitches are)
     uint32_t u[PYR_RPT][3], v[PYR_RPT][3], bbv[PYR_RPT];
     unsigned shv[PYR_RPT];
 #pragma unroll
     for (int r = 0; r < PYR_RPT; r++) {   // all loads of both rows first
-      int sy0 = yo[Yr[r]];
-      bbv[r] = (uint32_t)yb[Yr[r]];
+      int sy0 = yo[(uint32_t)Yr[r]];
+      bbv[r] = (uint32_t)yb[(uint32_t)Yr[r]];
       int sy1 = sy0 + 1;
       sy0 = sy0 < S.h ? sy0 : S.h - 1;
       sy1 = sy1 < S.h ? sy1 : S.h - 1;
-      const uintptr_t a0 = (uintptr_t)(sb + (size_t)__mul24(sy0, S.pstride) + base);
-      const uintptr_t a1 = (uintptr_t)(sb + (size_t)__mul24(sy1, S.pstride) + base);
-      shv[r] = (unsigned)(a0 & 3);   // same for both source rows: the row pitch is a multiple of 64
-      const uint32_t* q0 = (const uint32_t*)(a0 & ~(uintptr_t)3);
-      const uint32_t* q1 = (const uint32_t*)(a1 & ~(uintptr_t)3);
+      const uint32_t a0 = (uint32_t)(__mul24(sy0 + SD_EDGE, S.pstride) + base + SD_EDGE);
+      const uint32_t a1 = (uint32_t)(__mul24(sy1 + SD_EDGE, S.pstride) + base + SD_EDGE);
+      shv[r] = a0 & 3u;   // same for both source rows: the row pitch is a multiple of 64
+      const uint32_t* q0 = (const uint32_t*)(sb + (a0 & ~3u));
+      const uint32_t* q1 = (const uint32_t*)(sb + (a1 & ~3u));
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         u[r][k] = q0[k];
@@ -334,17 +339,14 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const Lev
       // 8 source bytes starting at sx[0], per row
       const uint32_t r0lo = __builtin_amdgcn_alignbyte(u[r][1], u[r][0], sh), r0hi = __builtin_amdgcn_alignbyte(u[r][2], u[r][1], sh);
       const uint32_t r1lo = __builtin_amdgcn_alignbyte(v[r][1], v[r][0], sh), r1hi = __builtin_amdgcn_alignbyte(v[r][2], v[r][1], sh);
-      const uint32_t p0a = __builtin_amdgcn_perm(r0hi, r0lo, selA), p0b = __builtin_amdgcn_perm(r0hi, r0lo, selB);
-      const uint32_t p1a = __builtin_amdgcn_perm(r1hi, r1lo, selA), p1b = __builtin_amdgcn_perm(r1hi, r1lo, selB);
       uint32_t pk = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int wa0 = (int)(ab[k] & 0xffff), wa1 = (int)(ab[k] >> 16);
-        const int p00 = (int)((p0a >> (8 * k)) & 0xff), p01 = (int)((p0b >> (8 * k)) & 0xff);
-        const int p10 = (int)((p1a >> (8 * k)) & 0xff), p11 = (int)((p1b >> (8 * k)) & 0xff);
-        const int h0 = __mul24(p00, wa0) + __mul24(p01, wa1);
-        const int h1 = __mul24(p10, wa0) + __mul24(p11, wa1);
-        const int ov = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
+        const us2 w = __builtin_bit_cast(us2, ab[k]);
+        const int h0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(r0hi, r0lo, selP[k])), w, 0u, false);
+        const int h1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(r1hi, r1lo, selP[k])), w, 0u, false);
+        // (b * (h >> 4)) >> 16 == mulhi(b << 12, h & ~15): one 32-bit multiply per source row (b <= 2048, h < 2^20)
+        const int ov = (int)(__umulhi((uint32_t)b0 << 12, (uint32_t)h0 & ~15u) + __umulhi((uint32_t)b1 << 12, (uint32_t)h1 & ~15u) + 2u) >> 2;
         pk |= (uint32_t)(ov < 0 ? 0 : (ov > 255 ? 255 : ov)) << (8 * k);
       }
       packed[r] = pk;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const Lev
   }
 #pragma unroll
   for (int r = 0; r < PYR_RPT; r++)
-    if (live[r]) *(uint32_t*)(dstb + (size_t)Yr[r] * L.pstride) = packed[r];
+    if (live[r]) *(uint32_t*)(dstb + (dst_x + (uint32_t)__mul24(Yr[r], L.pstride))) = packed[r];
 }
 
 // interior rows: padded columns [0, 20) and [20 + 4 G, roundup4(w + 38)); one thread per 4 columns
