@@ -520,14 +520,20 @@ __device__ unsigned long long g_fast_prof[8];
 //      emission (wave bands are contiguous in raster order, so per-wave counts give offsets).
 extern "C" __device__ __attribute__((const)) int __ockl_wfred_add_i32(int);
 
+#ifndef FAST_STAGE_DEPTH
+#define FAST_STAGE_DEPTH 12   // tile dwords in flight per thread while staging (256 threads x 12 x 4 B = 12 KB per round trip)
+#endif
+
 // 8 waves per SIMD: the kernel needed 65 VGPRs, one over the 64-register step; held to 64 it gains a resident wave per SIMD
 // and the whole extraction 5 % (169 k -> 177 k frames/s ORB-only)
-__global__ __launch_bounds__(256, 8) void k_fast_cells(const OrbPlan* __restrict__ P,
-                                                    const CellGeom* __restrict__ cells,
-                                                    const uint8_t* __restrict__ pyr,
-                                                    uint32_t* __restrict__ cand,
-                                                    int32_t* __restrict__ cell_count, int cell0,
-                                                    const uint8_t* __restrict__ src0, int src_stride, size_t src_frame_stride) {
+// Everything the workgroup needs besides its CellGeom arrives as kernel arguments (no dependent cell -> level -> plan loads):
+// img0 / frame_stride / pstride / edge describe the level's rows -- the padded pyramid level (edge = SD_EDGE), or, for level 0,
+// the caller's frames themselves (edge = 0; 4-byte aligned base and strides): FAST only touches interior pixels (the zones
+// start SD_EDGE - 3 px inside), so level 0 need not wait for the padded copy of the frame.
+__global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restrict__ cells, const uint8_t* __restrict__ img0,
+                                                    size_t frame_stride, int pstride, int edge, uint32_t* __restrict__ cand,
+                                                    uint32_t cand_per_frame, int32_t* __restrict__ cell_count, int ncells_total,
+                                                    int cell0, int th) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int wcnt[4];
   const int cell = blockIdx.x + cell0;   // launched per level: the cells of a level are contiguous
@@ -535,16 +541,11 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const OrbPlan* __restrict
   const int frame = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (C.zw <= 0 || C.zh <= 0) {
-    if (tid == 0) cell_count[(size_t)frame * P->ncells + cell] = 0;
+    if (tid == 0) cell_count[(size_t)frame * ncells_total + cell] = 0;
     return;
   }
-  const LevelGeom L = P->lv[C.level];
-  // Level 0 can be read straight from the caller's frames (src0 != NULL; 4-byte aligned base / strides): FAST only touches
-  // interior pixels (the zones start SD_EDGE - 3 px inside), so it need not wait for the padded copy of the frame.
-  const uint8_t* img = src0 ? src0 + (size_t)frame * src_frame_stride : pyr + (size_t)frame * P->pyr_frame_bytes + L.off;
-  const int pstride = src0 ? src_stride : L.pstride, edge = src0 ? 0 : SD_EDGE;
-  uint32_t* out = cand + (size_t)frame * P->cand_per_frame + C.cand_off;
-  const int th = P->thFAST;
+  const uint8_t* img = img0 + (size_t)frame * frame_stride;
+  uint32_t* out = cand + (size_t)frame * cand_per_frame + C.cand_off;
   const int zw = C.zw, zh = C.zh, S = C.strip_rows;
   const int xs = C.zx0 - 3 + edge;   // x of tile column 0 in the source rows (before alignment)
   const int xa = xs & ~3, sh = xs - xa;
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const OrbPlan* __restrict
   uint8_t* sc = smem + (size_t)TP * (S + 2 + 6);
   uint16_t* queue = (uint16_t*)(sc + (size_t)SP * (S + 2 + 2)) + (size_t)wave * QCAP;
   const unsigned magic = 0xFFFFFFFFu / (unsigned)zw + 1u;   // q / zw == umulhi(q, magic) for q < 2^16, zw < 2^12
+  const unsigned magic_tpw = 0xFFFFFFFFu / (unsigned)TPW + 1u;   // tile dword index / TPW (indices < 2^16: the tile is < 64 KB)
   const unsigned long long lt = lanemask_lt();
   int total = 0;
   FPROF_DECL;
@@ -566,24 +568,28 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const OrbPlan* __restrict
     const int sr0 = max(r0 - 1, 0), sr1 = min(r1 + 1, zh);   // zone rows whose scores are needed
     const int nsr = sr1 - sr0;
     const int npr = nsr + 6;
-    // ---- stage pixels (aligned words) and clear the score map
+    // ---- stage pixels (aligned words) and clear the score map.  The tile's dwords are numbered row-major and dealt to the
+    // 256 threads FAST_STAGE_DEPTH at a time, all loads before the first LDS store: a tile of up to 12 KB is ONE global round
+    // trip (the strip's life is mostly this wait: with 8 rows per wave and batch it was three)
     {
       const uint8_t* g = img + (size_t)(C.zy0 + sr0 - 3 + edge) * pstride + xa;
-      // loads are issued 8 rows at a time before the first LDS store: one global round trip per batch
-      for (int wc = lane; wc < TPW; wc += 64)
-        for (int row0 = wave; row0 < npr; row0 += 32) {
-          uint32_t v[8];
+      const int ndw = __mul24(TPW, npr);
+      int t0 = tid;
+      asm volatile("" : "+v"(t0));   // opaque per strip: otherwise the row / column of every slot is hoisted out of the strip loop and spilled
+      for (int i0 = t0; i0 < ndw; i0 += 256 * FAST_STAGE_DEPTH) {
+        uint32_t v[FAST_STAGE_DEPTH];
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const int row = row0 + 4 * j;
-            v[j] = row < npr ? *(const uint32_t*)(g + (size_t)__mul24(row, pstride) + wc * 4) : 0u;
-          }
-#pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const int row = row0 + 4 * j;
-            if (row < npr) ((uint32_t*)tile)[__mul24(row, TPW) + wc] = v[j];
-          }
+        for (int j = 0; j < FAST_STAGE_DEPTH; j++) {
+          const int i = i0 + 256 * j;
+          const int row = (int)__umulhi((unsigned)i, magic_tpw), wc = i - __mul24(row, TPW);
+          v[j] = i < ndw ? *(const uint32_t*)(g + (uint32_t)(__mul24(row, pstride) + wc * 4)) : 0u;
         }
+#pragma unroll
+        for (int j = 0; j < FAST_STAGE_DEPTH; j++) {
+          const int i = i0 + 256 * j;
+          if (i < ndw) ((uint32_t*)tile)[i] = v[j];
+        }
+      }
       const int nsc = ((nsr + 2) * SP) >> 2;
       for (int i = tid; i < nsc; i += 256) ((uint32_t*)sc)[i] = 0;
     }
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const OrbPlan* __restrict
     __syncthreads();
     FPROF(6);
   }
-  if (tid == 0) cell_count[(size_t)frame * P->ncells + cell] = min(total, (int)C.cap);
+  if (tid == 0) cell_count[(size_t)frame * ncells_total + cell] = min(total, (int)C.cap);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1319,8 +1325,8 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   if (fast0_direct) {
     if (prof) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
     fast_started = true;
-    hipLaunchKernelGGL(k_fast_cells, dim3(P.lv[0].ncells, n), dim3(256), hp.fast_lds_bytes, h->fast_stream, h->d_plan, h->d_cells,
-                       h->d_pyr, h->d_cand, h->d_cell_count, P.lv[0].cell0, d_imgs, stride, frame_stride);
+    hipLaunchKernelGGL(k_fast_cells, dim3(P.lv[0].ncells, n), dim3(256), hp.fast_lds_bytes, h->fast_stream, h->d_cells, d_imgs,
+                       frame_stride, stride, 0, h->d_cand, P.cand_per_frame, h->d_cell_count, P.ncells, P.lv[0].cell0, P.thFAST);
   }
   for (int l = 0; l < P.nlevels; l++) {
     const LevelGeom& L = P.lv[l];
@@ -1348,8 +1354,9 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
       SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_level[l], 0));
       if (prof && !fast_started) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
       fast_started = true;
-      hipLaunchKernelGGL(k_fast_cells, dim3(L.ncells, n), dim3(256), hp.fast_lds_bytes, h->fast_stream, h->d_plan, h->d_cells,
-                         h->d_pyr, h->d_cand, h->d_cell_count, L.cell0, (const uint8_t*)nullptr, 0, (size_t)0);
+      hipLaunchKernelGGL(k_fast_cells, dim3(L.ncells, n), dim3(256), hp.fast_lds_bytes, h->fast_stream, h->d_cells,
+                         (const uint8_t*)h->d_pyr + L.off, (size_t)P.pyr_frame_bytes, L.pstride, SD_EDGE, h->d_cand, P.cand_per_frame,
+                         h->d_cell_count, P.ncells, L.cell0, P.thFAST);
     }
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], s));
