@@ -497,16 +497,32 @@ __device__ __forceinline__ int fast_ring_score(const uint8_t* __restrict__ c, in
 
 #ifdef SD_PNP_PROF   // stage timers of k_fast_cells (tools/prof_select.py --fast): cycles of thread 0 per phase
 __device__ unsigned long long g_fast_prof[8];
-#define FPROF_DECL long long _pt = clock64()
-#define FPROF(i)                                                                             \
-  do {                                                                                       \
-    long long _n = clock64();                                                                \
-    if (threadIdx.x == 0) atomicAdd(&g_fast_prof[i], (unsigned long long)(_n - _pt));        \
-    _pt = _n;                                                                                \
+// one record per workgroup, plain stores (hot-address atomics from 150 k workgroups back up the memory pipeline the tile
+// loads go through and inflate the very phase being measured); summed on the host
+#define FPROF_FRAMES 256
+#define FPROF_CELLS 192
+__device__ unsigned long long g_fast_prof_wg[(size_t)FPROF_FRAMES * FPROF_CELLS * 8];
+// per-workgroup sums in LDS, one global atomic per phase at the end of the kernel: an atomic per phase and strip would sit in
+// vmcnt and be waited for by the next tile load (the first version of these timers charged that wait to "stage")
+#define FPROF_DECL                                   \
+  __shared__ unsigned long long s_fprof[8];          \
+  if (threadIdx.x < 8) s_fprof[threadIdx.x] = 0;     \
+  long long _pt = clock64()
+#define FPROF(i)                                                                 \
+  do {                                                                           \
+    long long _n = clock64();                                                    \
+    if (threadIdx.x == 0) s_fprof[i] += (unsigned long long)(_n - _pt);          \
+    _pt = _n;                                                                    \
+  } while (0)
+#define FPROF_FLUSH                                                                                                   \
+  do {                                                                                                                \
+    if (threadIdx.x == 0 && blockIdx.y < FPROF_FRAMES && cell < FPROF_CELLS)                                          \
+      for (int _i = 0; _i < 8; _i++) g_fast_prof_wg[((size_t)blockIdx.y * FPROF_CELLS + cell) * 8 + _i] = s_fprof[_i]; \
   } while (0)
 #else
 #define FPROF_DECL
 #define FPROF(i)
+#define FPROF_FLUSH
 #endif
 
 // Structure of one strip (a cell is one strip unless it is too large for LDS):
@@ -590,6 +606,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
           if (i < ndw) ((uint32_t*)tile)[i] = v[j];
         }
       }
+      FPROF(7);   // kernel / strip start -> this wave's tile words are in LDS
       const int nsc = ((nsr + 2) * SP) >> 2;
       for (int i = tid; i < nsc; i += 256) ((uint32_t*)sc)[i] = 0;
     }
@@ -689,6 +706,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
     FPROF(6);
   }
   if (tid == 0) cell_count[(size_t)frame * ncells_total + cell] = min(total, (int)C.cap);
+  FPROF_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1496,8 +1514,16 @@ int read_sel_prof(unsigned long long* out64, int reset) {   // [0..55] select [l
 #ifdef SD_PNP_PROF
   SD_HIP_CHECK(hipDeviceSynchronize());
   SD_HIP_CHECK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_sel_prof), 64 * sizeof(unsigned long long)));
-  unsigned long long f[8];
-  SD_HIP_CHECK(hipMemcpyFromSymbol(f, HIP_SYMBOL(g_fast_prof), sizeof(f)));
+  unsigned long long f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  {
+    std::vector<unsigned long long> wg((size_t)FPROF_FRAMES * FPROF_CELLS * 8);
+    SD_HIP_CHECK(hipMemcpyFromSymbol(wg.data(), HIP_SYMBOL(g_fast_prof_wg), wg.size() * 8));
+    for (size_t i = 0; i < wg.size(); i++) f[i & 7] += wg[i];
+    if (reset) {
+      std::fill(wg.begin(), wg.end(), 0ull);
+      SD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fast_prof_wg), wg.data(), wg.size() * 8));
+    }
+  }
   for (int l = 0; l < 8; l++) out64[l * 8 + 7] = f[l];   // slot 7 of every level row carries FAST phase l
   if (reset) {
     unsigned long long z[64] = {};

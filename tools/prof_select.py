@@ -31,6 +31,8 @@ for l in range(8):
 print("sum   " + " ".join(f"{v[:, i].sum():20.0f}" for i in range(7)) + f" {v[:, :7].sum():12.0f}")
 fn = ["stage+clear", "A compass", "B1 ring test", "B2 scores", "(barrier)", "C nms+emit", "(barrier)"]
 print("k_fast_cells, cycles of thread 0 per frame (sum over the 148 cells):")
+v[:, 7] *= reps   # the FAST records are per workgroup and overwritten by every call: they hold ONE call, not `reps`
 for i, n in enumerate(fn):
     print(f"  {n:16s} {v[i, 7]:12.0f}")
-print(f"  {'total':16s} {v[:7, 7].sum():12.0f}")
+print(f"  {'(own tile words loaded + stored, first part of stage)':16s} {v[7, 7]:12.0f}")
+print(f"  {'total':16s} {v[:8, 7].sum():12.0f}")
