@@ -904,6 +904,180 @@ __global__ __launch_bounds__(64 * SEL_WAVES, 8) void k_select_level(const OrbPla
 }
 
 // ------------------------------------------------------------------------------------------
+// Split selection (the default): the same three steps as k_select_level, one launch each, so that no wave sits idle through
+// another step's serial part -- k_select_level keeps 8 waves resident per (level, frame) while ONE thread runs the quota loop
+// and ONE wave the level-wide retainBest, and gives a level with 30 cells 4 rounds of 8 waves.
+//   k_select_quota   one wave per frame, lane l runs level l's quota loop (counts staged through LDS); writes the kept count
+//                    and list offset of every cell and the list length of every level
+//   k_select_cells   one wave per (cell, frame): retainBest of the cell in LDS, survivors to their slot of the level list in
+//                    HBM; k_select_bigcells: the (rare) cells with more candidates than that kernel's small buffer
+//   k_select_final   one wave per (level, frame): level-wide retainBest (list through LDS), selected keys + count
+// Same helpers (introselect replay), same order of operations inside every step: results are identical to k_select_level's.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_select_quota(const OrbPlan* __restrict__ P, const CellGeom* __restrict__ cells,
+                                                     const int32_t* __restrict__ cell_count, int32_t* __restrict__ cell_keep,
+                                                     int32_t* __restrict__ cell_off, int32_t* __restrict__ lvl_m) {
+  extern __shared__ __attribute__((aligned(16))) int s_q[];   // [4][ncells]: total, evaluated / bNoMore, retain, offset
+  const int frame = blockIdx.x, lane = threadIdx.x, nc = P->ncells;
+  int* s_total = s_q;
+  int* s_flag = s_q + nc;
+  int* s_retain = s_q + 2 * nc;
+  int* s_offv = s_q + 3 * nc;
+  const int32_t* cc = cell_count + (size_t)frame * nc;
+  for (int c = lane; c < nc; c += 64) {
+    s_total[c] = cc[c];
+    s_flag[c] = cells[c].evaluated;
+  }
+  sdsel::wave_fence();
+  if (lane < P->nlevels) {
+    const LevelGeom& L = P->lv[lane];
+    int M = 0;
+    if (L.ncells > 0 && L.quota > 0) {
+      const int nC = L.ncells, c0 = L.cell0, nfc = L.nfeaturesCell;
+      int nNoMore = 0, nToDistribute = 0;
+      for (int c = c0; c < c0 + nC; c++) {
+        const int nKeys = s_total[c];
+        if (!s_flag[c]) {                // cell not evaluated: the reference `continue`s (nToRetain=0, bNoMore=false)
+          s_retain[c] = 0;
+          s_flag[c] = 0;                 // from here on: the bNoMore flag
+          continue;
+        }
+        if (nKeys > nfc) {
+          s_retain[c] = nfc;
+          s_flag[c] = 0;
+        } else {
+          s_retain[c] = nKeys;
+          nToDistribute += nfc - nKeys;
+          s_flag[c] = 1;
+          nNoMore++;
+        }
+      }
+      while (nToDistribute > 0 && nNoMore < nC) {
+        // nfeaturesCell + ceil((float)nToDistribute/(nCells-nNoMore))
+        const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nC - nNoMore));
+        nToDistribute = 0;
+        for (int c = c0; c < c0 + nC; c++) {
+          if (!s_flag[c]) {
+            if (s_total[c] > nNew) {
+              s_retain[c] = nNew;
+            } else {
+              s_retain[c] = s_total[c];
+              nToDistribute += nNew - s_total[c];
+              s_flag[c] = 1;
+              nNoMore++;
+            }
+          }
+        }
+      }
+      for (int c = c0; c < c0 + nC; c++) {   // kept counts and their offsets in the level list
+        const int k = min(s_total[c], s_retain[c]);
+        s_retain[c] = k;
+        s_offv[c] = M;
+        M += k;
+      }
+    } else {
+      for (int c = L.cell0; c < L.cell0 + max(L.ncells, 0); c++) { s_retain[c] = 0; s_offv[c] = 0; }
+    }
+    lvl_m[(size_t)frame * P->nlevels + lane] = M;
+  }
+  sdsel::wave_fence();
+  for (int c = lane; c < nc; c += 64) {
+    cell_keep[(size_t)frame * nc + c] = s_retain[c];
+    cell_off[(size_t)frame * nc + c] = s_offv[c];
+  }
+}
+
+__global__ __launch_bounds__(64) void k_select_cells(const OrbPlan* __restrict__ P, const CellGeom* __restrict__ cells,
+                                                     uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_count,
+                                                     const int32_t* __restrict__ cell_keep, const int32_t* __restrict__ cell_off,
+                                                     uint32_t* __restrict__ lvl_scratch, int buf_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_cellbuf[];   // [buf_cap] candidates | u16 [2 * WAVE_SEL_CAP] stop tables
+  const int c = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x, nc = P->ncells;
+  const int keep = cell_keep[(size_t)frame * nc + c];
+  if (keep <= 0) return;
+  const int n = cell_count[(size_t)frame * nc + c], o = cell_off[(size_t)frame * nc + c];
+  const CellGeom cg = cells[c];
+  uint32_t* src = cand + (size_t)frame * P->cand_per_frame + cg.cand_off;
+  uint32_t* glist = lvl_scratch + (size_t)frame * P->cand_per_frame + P->lv[cg.level].cand_off + o;
+  if (n > buf_cap) return;   // k_select_bigcells
+  lds_u32* buf = (lds_u32*)s_cellbuf;
+  for (int i = lane; i < n; i += 64) buf[i] = src[i];
+  sdsel::wave_fence();
+  if (n > keep) sdsel::wave_nth_element(buf, n, keep, (sdsel::lds_u16*)(s_cellbuf + buf_cap));
+  for (int i = lane; i < keep; i += 64) glist[i] = buf[i];
+}
+
+// cells with more candidates than k_select_cells' buffer (dense texture, noise): one wave per (level, frame) walks its level's
+// cells and trims those, one at a time, in a buffer of big_cap entries; beyond that the serial replay in HBM (lane 0).
+// On ordinary frames every workgroup finds nothing to do and leaves after one load.
+__global__ __launch_bounds__(64) void k_select_bigcells(const OrbPlan* __restrict__ P, const CellGeom* __restrict__ cells,
+                                                        uint32_t* __restrict__ cand, const int32_t* __restrict__ cell_count,
+                                                        const int32_t* __restrict__ cell_keep, const int32_t* __restrict__ cell_off,
+                                                        uint32_t* __restrict__ lvl_scratch, int small_cap, int big_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_cellbuf[];   // [big_cap] candidates | u16 [2 * WAVE_SEL_CAP] stop tables
+  const int level = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x, nc = P->ncells;
+  const LevelGeom& L = P->lv[level];
+  if (L.ncells <= 0 || L.quota <= 0) return;
+  for (int c0 = 0; c0 < L.ncells; c0 += 64) {
+    const int cl = L.cell0 + c0 + lane;
+    const bool mine = c0 + lane < L.ncells && cell_count[(size_t)frame * nc + cl] > small_cap && cell_keep[(size_t)frame * nc + cl] > 0;
+    unsigned long long todo = __ballot(mine);
+    while (todo) {
+      const int c = L.cell0 + c0 + __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int n = cell_count[(size_t)frame * nc + c], keep = cell_keep[(size_t)frame * nc + c], o = cell_off[(size_t)frame * nc + c];
+      uint32_t* src = cand + (size_t)frame * P->cand_per_frame + cells[c].cand_off;
+      uint32_t* glist = lvl_scratch + (size_t)frame * P->cand_per_frame + L.cand_off + o;
+      if (n <= big_cap) {
+        lds_u32* buf = (lds_u32*)s_cellbuf;
+        for (int i = lane; i < n; i += 64) buf[i] = src[i];
+        sdsel::wave_fence();
+        if (n > keep) sdsel::wave_nth_element(buf, n, keep, (sdsel::lds_u16*)(s_cellbuf + big_cap));
+        for (int i = lane; i < keep; i += 64) glist[i] = buf[i];
+        sdsel::wave_fence();   // the buffer is reused by the next cell
+      } else if (lane == 0) {
+        if (n > keep) sdsel::nth_element(src, n, keep);
+        for (int i = 0; i < keep; i++) glist[i] = src[i];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_select_final(const OrbPlan* __restrict__ P, const int32_t* __restrict__ lvl_m,
+                                                     uint32_t* __restrict__ lvl_scratch, uint32_t* __restrict__ sel,
+                                                     int32_t* __restrict__ sel_count) {
+  __shared__ uint32_t s_list[SEL_LIST_CAP];
+  __shared__ uint16_t s_tmp[2 * WAVE_SEL_CAP];
+  const int level = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x;
+  const LevelGeom& L = P->lv[level];
+  int32_t* out_n = sel_count + (size_t)frame * P->nlevels + level;
+  if (L.ncells <= 0 || L.quota <= 0) {
+    if (lane == 0) *out_n = 0;
+    return;
+  }
+  const int M = lvl_m[(size_t)frame * P->nlevels + level];
+  uint32_t* glist = lvl_scratch + (size_t)frame * P->cand_per_frame + L.cand_off;
+  uint32_t* dst = sel + (size_t)frame * P->nsel + L.sel_off;
+  int Mout = M;
+  if (M > L.quota) {
+    Mout = L.quota;
+    if (M <= SEL_LIST_CAP) {
+      for (int i = lane; i < M; i += 64) s_list[i] = glist[i];
+      sdsel::wave_fence();
+      sdsel::wave_nth_element((lds_u32*)s_list, M, L.quota, (sdsel::lds_u16*)s_tmp);
+      for (int i = lane; i < Mout; i += 64) dst[i] = s_list[i];
+    } else {
+      if (lane == 0) sdsel::nth_element(glist, M, L.quota);
+      sdsel::wave_fence();
+      for (int i = lane; i < Mout; i += 64) dst[i] = glist[i];
+    }
+  } else {
+    for (int i = lane; i < Mout; i += 64) dst[i] = glist[i];
+  }
+  if (lane == 0) *out_n = Mout;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_blur: GaussianBlur(7x7, sigma 2, REFLECT_101) in OpenCV's 8-bit fixed point: integer taps
 // round(g*256) = {18,34,49,55,49,34,18}, row pass in int32, column pass (sum + 2^15) >> 16,
 // saturated.  The padded pyramid already holds the REFLECT_101 border, so no border logic.
@@ -1235,12 +1409,13 @@ static const char* kStageNames[ST_COUNT] = {"pyramid", "fast_nms", "select", "bl
 
 static int free_geom(sd_orb* h) {
   void* ptrs[] = {h->d_cells, h->d_tiles, h->d_coef, h->pyr_set[0], h->pyr_set[1], h->d_blur, h->d_cand, h->d_scratch,
-                  h->d_cell_count, h->d_sel, h->d_sel_count};
+                  h->d_cell_count, h->d_sel, h->d_sel_count, h->d_cell_keep, h->d_cell_off, h->d_lvl_m};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->pyr_set[0] = h->pyr_set[1] = nullptr;
   h->d_cells = nullptr; h->d_tiles = nullptr; h->d_coef = nullptr; h->d_pyr = nullptr; h->d_blur = nullptr;
   h->d_cand = nullptr; h->d_scratch = nullptr; h->d_cell_count = nullptr; h->d_sel = nullptr; h->d_sel_count = nullptr;
+  h->d_cell_keep = nullptr; h->d_cell_off = nullptr; h->d_lvl_m = nullptr;
   return SD_OK;
 }
 
@@ -1284,6 +1459,9 @@ static int build_geometry(sd_orb* h, const HostPlan& hp) {
   SD_HIP_CHECK(hipMalloc(&h->d_cell_count, std::max<size_t>(hp.plan.ncells, 1) * B * 4));
   SD_HIP_CHECK(hipMalloc(&h->d_sel, std::max<size_t>(hp.plan.nsel, 1) * B * 4));
   SD_HIP_CHECK(hipMalloc(&h->d_sel_count, (size_t)h->nlevels * B * 4));
+  SD_HIP_CHECK(hipMalloc(&h->d_cell_keep, std::max<size_t>(hp.plan.ncells, 1) * B * 4));
+  SD_HIP_CHECK(hipMalloc(&h->d_cell_off, std::max<size_t>(hp.plan.ncells, 1) * B * 4));
+  SD_HIP_CHECK(hipMalloc(&h->d_lvl_m, (size_t)h->nlevels * B * 4));
   SD_HIP_CHECK(hipMemsetAsync(h->d_blur, 0, hp.plan.pyr_frame_bytes * B + slack, h->stream));
   if (!hp.cells.empty())
     SD_HIP_CHECK(hipMemcpyAsync(h->d_cells, hp.cells.data(), hp.cells.size() * sizeof(CellGeom), hipMemcpyHostToDevice, h->stream));
@@ -1394,8 +1572,25 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_fast_done, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[9], s));
   const int sel_cap = hp.max_cell_pixels > 12000 ? 1024 : 512;
-  hipLaunchKernelGGL(k_select_level, dim3(P.nlevels, n), dim3(64 * SEL_WAVES), (size_t)SEL_WAVES * sel_cap * 4, s, h->d_plan, h->d_cells, h->d_cand,
-                     h->d_cell_count, h->d_scratch, h->d_sel, h->d_sel_count, sel_cap);
+  const char* e_split = getenv("SD_SELECT_SPLIT");   // "0": the single-kernel variant (A/B, tests)
+  const bool sel_split = !(e_split && e_split[0] == '0');
+  if (sel_split && P.ncells > 0) {
+    hipLaunchKernelGGL(k_select_quota, dim3(n), dim3(64), (size_t)P.ncells * 16, s, h->d_plan, h->d_cells, h->d_cell_count, h->d_cell_keep,
+                       h->d_cell_off, h->d_lvl_m);
+    // small buffer = 2 x sel_cap entries (5 KB at VGA: 32 one-wave workgroups per CU; 4 x was 0.385 ms, 2 x and 1 x 0.275 ms);
+    // big buffer = what k_select_level had (SEL_WAVES x sel_cap)
+    int small_cap = 2 * sel_cap, big_cap = SEL_WAVES * sel_cap;
+    if (const char* e = getenv("SD_SELECT_SMALLCAP")) small_cap = std::max(1, std::min(atoi(e), small_cap));   // tests: force the other paths
+    if (const char* e = getenv("SD_SELECT_BIGCAP")) big_cap = std::max(small_cap, std::min(atoi(e), big_cap));
+    hipLaunchKernelGGL(k_select_cells, dim3(P.ncells, n), dim3(64), (size_t)small_cap * 4 + 2 * WAVE_SEL_CAP * 2, s, h->d_plan, h->d_cells,
+                       h->d_cand, h->d_cell_count, h->d_cell_keep, h->d_cell_off, h->d_scratch, small_cap);
+    hipLaunchKernelGGL(k_select_bigcells, dim3(P.nlevels, n), dim3(64), (size_t)big_cap * 4 + 2 * WAVE_SEL_CAP * 2, s, h->d_plan, h->d_cells,
+                       h->d_cand, h->d_cell_count, h->d_cell_keep, h->d_cell_off, h->d_scratch, small_cap, big_cap);
+    hipLaunchKernelGGL(k_select_final, dim3(P.nlevels, n), dim3(64), 0, s, h->d_plan, h->d_lvl_m, h->d_scratch, h->d_sel, h->d_sel_count);
+  } else {
+    hipLaunchKernelGGL(k_select_level, dim3(P.nlevels, n), dim3(64 * SEL_WAVES), (size_t)SEL_WAVES * sel_cap * 4, s, h->d_plan, h->d_cells, h->d_cand,
+                       h->d_cell_count, h->d_scratch, h->d_sel, h->d_sel_count, sel_cap);
+  }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[7], s));
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_blur_done, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[4], s));

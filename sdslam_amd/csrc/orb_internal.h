@@ -54,6 +54,9 @@ struct sd_orb {
   int32_t* d_cell_count = nullptr;
   uint32_t* d_sel = nullptr;
   int32_t* d_sel_count = nullptr;
+  int32_t* d_cell_keep = nullptr;   // split selection: kept count / offset in the level list per (frame, cell), list length per (frame, level)
+  int32_t* d_cell_off = nullptr;
+  int32_t* d_lvl_m = nullptr;
   sd_keypoint* d_kps = nullptr;
   sd_keypoint* d_kps_un = nullptr;   // Frame::mvKeysUn (== d_kps when k1 == 0)
   bool have_dist = false;

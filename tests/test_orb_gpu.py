@@ -102,6 +102,25 @@ def test_edge_inputs(sd, oracle):
     ext.close()
 
 
+@pytest.mark.parametrize("env", [{"SD_SELECT_SMALLCAP": "48"}, {"SD_SELECT_SMALLCAP": "48", "SD_SELECT_BIGCAP": "160"},
+                                 {"SD_SELECT_SPLIT": "0"}])
+def test_selection_paths(sd, oracle, env, monkeypatch):
+    """The selection's rarely used paths give the same keys: cells larger than k_select_cells' buffer (trimmed by
+    k_select_bigcells in its LDS buffer), cells larger than that one too (serial replay in HBM), and the single-kernel
+    variant (SD_SELECT_SPLIT=0).  Textured frame and pure noise (densest lists, ties everywhere)."""
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 1)
+    ora = oracle.OrbOracle(1000, 1.2, 8, 20)
+    rng = np.random.default_rng(5)
+    for img in (make_image(61), rng.integers(0, 256, size=(480, 640)).astype(np.uint8)):
+        k, d = ext(img)
+        ok, od = _compare_frame(oracle, ext, ora, img, 0, 8)
+        assert len(ok) > 500
+        assert np.array_equal(k, ok) and np.array_equal(d, od)
+    ext.close()
+
+
 @pytest.mark.parametrize("shape,cfg", [((479, 637), (1000, 1.2, 8, 20)), ((242, 321), (500, 1.2, 6, 20)),
                                        ((480, 640), (1000, 2.0, 4, 20)), ((360, 486), (800, 1.5, 5, 12))])
 def test_odd_geometries_all_stages(sd, oracle, shape, cfg):
