@@ -185,7 +185,7 @@ def cpu_baseline(scenes, lasts, T0s, rs, pose_solver="pnp", locals_=None, budget
 
 # ------------------------------------------------------------------------------------------------ PMC / VALU figures
 STAGE_KERNELS = {"pyramid": ["k_pyr_resize", "k_pyr_edges", "k_pyr_rows", "k_pyr_level", "k_pyr_fused"], "fast_nms": ["k_fast_cells"],
-                 "select": ["k_select_level"], "blur": ["k_blur"], "orient_desc": ["k_orient_desc"], "image_align": ["k_align"],
+                 "select": ["k_select_quota", "k_select_cells", "k_select_bigcells", "k_select_final", "k_select_level"], "blur": ["k_blur"], "orient_desc": ["k_orient_desc"], "image_align": ["k_align"],
                  "search_by_projection": ["k_match"], "pnp_ransac": ["k_pnp"], "search_by_points": ["k_search_points"]}
 PMC_FRAMES = 1024       # frames per launch in the committed PMC passes (tools/run_profiles.sh: default batch)
 
@@ -213,7 +213,7 @@ def pmc_for_stage(stage, batch):
             continue
         found = True
         # launches per step: relative to a kernel that runs once per step (the pyramid and FAST kernels run per level)
-        calls = max(1, round(e.get("duration_ns_samples", 1) / max(d.get("k_select_level", {}).get("duration_ns_samples", 1), 1)))
+        calls = max(1, round(e.get("duration_ns_samples", 1) / max((d.get("k_select_final") or d.get("k_select_level") or {}).get("duration_ns_samples", 1), 1)))
         tot += calls * (e["FETCH_bytes_corrected_per_launch"] + e.get("WRITE_bytes_per_launch", 0.0))
         valu += calls * e.get("SQ_INSTS_VALU_per_launch", 0.0)
         dur += calls * e.get("duration_ns_per_launch", 0.0)

@@ -278,7 +278,7 @@ int sd_track_get_pnp(sd_track* h, int frame0, int n_frames, float* Tcw_rowmajor,
 /* Stage cycle counters of k_pnp (only in a library built with -DSD_PNP_PROF; tools/prof_pnp.py) */
 int sd_debug_pnp_prof(unsigned long long* out32, int reset);
 int sd_debug_align_prof(unsigned long long* out16, int reset); /* k_align phases */
-int sd_debug_sel_prof(unsigned long long* out64, int reset);   /* k_select_level: [level][slot] */
+int sd_debug_sel_prof(unsigned long long* out64, int reset);   /* out64[8 * i + 7] = k_fast_cells phase i (cycles), rest 0 */
 int sd_debug_epnp(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy,
                   double* R9, double* t3, double* reproj_err);
 int sd_track_debug_read(sd_track* h, int which, int frame, void* out, size_t bytes);

@@ -9,7 +9,7 @@
 //   k_pyr_rows       ... copyMakeBorder rows       (top / bottom border rows = copies of finished rows)
 //   k_pyr_level      same, single generic pass     (exact-2x INTER_AREA levels, byte-unaligned inputs, tiny levels)
 //   k_fast_cells     cv::FAST per grid cell        src/ORBextractor.cc:501-552 (FAST-9/16, score, cell-local 3x3 NMS)
-//   k_select_level   quota loop + retainBest       src/ORBextractor.cc:554-605 (wave-parallel libstdc++ introselect replay)
+//   k_select_*       quota loop + retainBest       src/ORBextractor.cc:554-605 (wave-parallel libstdc++ introselect replay)
 //   k_blur           GaussianBlur 7x7 s=2          src/ORBextractor.cc:659-660 (8-bit fixed point, separable)
 //   k_orient_desc    IC_Angle + steered rBRIEF     src/ORBextractor.cc:78-143, 608-618, 669-674
 //   k_undistort      Frame::UndistortKeyPoints     src/Frame.cc:335-366
@@ -496,7 +496,6 @@ __device__ __forceinline__ int fast_ring_score(const uint8_t* __restrict__ c, in
 }
 
 #ifdef SD_PNP_PROF   // stage timers of k_fast_cells (tools/prof_select.py --fast): cycles of thread 0 per phase
-__device__ unsigned long long g_fast_prof[8];
 // one record per workgroup, plain stores (hot-address atomics from 150 k workgroups back up the memory pipeline the tile
 // loads go through and inflate the very phase being measured); summed on the host
 #define FPROF_FRAMES 256
@@ -710,209 +709,29 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
 }
 
 // ------------------------------------------------------------------------------------------
-// k_select_level: one workgroup (4 waves) per (level, frame).
-//   1. quota redistribution loop            src/ORBextractor.cc:541-575 (serial, thread 0)
-//   2. per-cell retainBest + resize         :586-588   one WAVE per cell: the cell's candidates are
-//      staged into the wave's LDS buffer, trimmed with the wave-parallel introselect replay
-//      (introselect_wave.h) and the survivors written straight to their slot of the level list
-//      (:591-597; the kept counts, hence the offsets, are known after step 1)
-//   3. level-wide retainBest + resize       :601-604   wave 0, same replay, list in LDS
-// Cells with more candidates than the wave buffer, or levels whose list exceeds the LDS list, fall
-// back to the serial replay in HBM (never seen on VGA frames; kept for correctness).
+// Selection (src/ORBextractor.cc:541-605), three steps, one launch each (k_select_quota, k_select_cells [+ k_select_bigcells],
+// k_select_final):
+//   1. quota redistribution loop            :541-575 (serial per level)
+//   2. per-cell retainBest + resize         :586-588   one WAVE per cell: the cell's candidates are staged into LDS, trimmed
+//      with the wave-parallel introselect replay (introselect_wave.h) and the survivors written straight to their slot of the
+//      level list (:591-597; the kept counts, hence the offsets, are known after step 1)
+//   3. level-wide retainBest + resize       :601-604   one wave per level, same replay, list in LDS
+// Cells with more candidates than the LDS buffers, or levels whose list exceeds the LDS list, fall back to the serial replay
+// in HBM (never seen on VGA / 720p frames; kept for correctness, tests/test_orb_gpu.py::test_selection_paths).
+// r1 / early r2 ran the three steps in ONE kernel (8 waves per (level, frame)): those waves sat idle through the serial quota
+// loop and the one-wave level step, and a level with 30 cells needed 4 rounds of 8 waves: 0.52 ms against 0.28 ms split.
 // ------------------------------------------------------------------------------------------
-#ifdef SD_PNP_PROF   // stage timers (tools/prof_select.py): cycles of thread 0, [level][slot], summed over frames
-__device__ unsigned long long g_sel_prof[64];
-#define SPROF_DECL long long _pt = clock64()
-#define SPROF(i)                                                                                        \
-  do {                                                                                                  \
-    long long _n = clock64();                                                                           \
-    if (threadIdx.x == 0) atomicAdd(&g_sel_prof[blockIdx.x * 8 + (i)], (unsigned long long)(_n - _pt)); \
-    _pt = _n;                                                                                           \
-  } while (0)
-#else
-#define SPROF_DECL
-#define SPROF(i)
-#endif
-
-#define SEL_WAVES 8
-// candidates of one cell staged per wave (dynamic LDS, chosen per geometry by select_cell_cap()): 512 keeps four workgroups
-// per CU on VGA-sized cells; frames with large cells (1280x720: 311 x 98 pixels) take 1024.  Larger cells: wave 0 with all the
-// waves' buffers as one
+#define SEL_WAVES 8         // big-cell buffer = SEL_WAVES x the per-geometry cell capacity (what the single kernel's 8 waves held)
 #define SEL_LIST_CAP 1536   // level list (LDS)
 #define SEL_MAX_CELLS 512
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
-// 8 waves per SIMD (63 VGPRs instead of 78) + 36.9 KB of LDS: four workgroups per CU instead of three (0.63 -> 0.51 ms)
-__global__ __launch_bounds__(64 * SEL_WAVES, 8) void k_select_level(const OrbPlan* __restrict__ P,
-                                                                const CellGeom* __restrict__ cells,
-                                                                uint32_t* __restrict__ cand,
-                                                                const int32_t* __restrict__ cell_count,
-                                                                uint32_t* __restrict__ lvl_scratch,
-                                                                uint32_t* __restrict__ sel,
-                                                                int32_t* __restrict__ sel_count, int SEL_CELL_CAP) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_buf_dyn[];   // [SEL_WAVES][SEL_CELL_CAP]
-  __shared__ uint32_t s_list[SEL_LIST_CAP];
-  __shared__ uint16_t s_tmp[SEL_WAVES][2 * WAVE_SEL_CAP];   // stop tables of the wave-parallel partition
-  __shared__ int s_total[SEL_MAX_CELLS];
-  __shared__ int s_retain[SEL_MAX_CELLS];
-  __shared__ int s_off[SEL_MAX_CELLS + 1];   // bNoMore flags during the quota loop, then kept offsets
-  __shared__ int s_M;
-  const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const LevelGeom L = P->lv[level];
-  int32_t* out_n = sel_count + (size_t)frame * P->nlevels + level;
-  if (L.ncells <= 0 || L.quota <= 0) {
-    if (tid == 0) *out_n = 0;
-    return;
-  }
-  const int nC = L.ncells;
-  const CellGeom* cg = cells + L.cell0;
-  const int32_t* cc = cell_count + (size_t)frame * P->ncells + L.cell0;
-  uint32_t* gcand = cand + (size_t)frame * P->cand_per_frame;
-
-  SPROF_DECL;
-  for (int c = tid; c < nC; c += 64 * SEL_WAVES) {
-    s_total[c] = cc[c];
-    s_off[c] = cg[c].evaluated;
-  }
-  __syncthreads();
-  SPROF(0);
-  if (tid == 0) {
-    // quota loop (serial by definition)
-    const int nfc = L.nfeaturesCell;
-    int nNoMore = 0, nToDistribute = 0;
-    for (int c = 0; c < nC; c++) {
-      int nKeys = s_total[c];
-      if (!s_off[c]) {                 // cell not evaluated: the reference `continue`s (nToRetain=0, bNoMore=false)
-        s_retain[c] = 0;
-        s_off[c] = 0;                  // bNoMore flag lives in s_off during the loop
-        continue;
-      }
-      if (nKeys > nfc) {
-        s_retain[c] = nfc;
-        s_off[c] = 0;
-      } else {
-        s_retain[c] = nKeys;
-        nToDistribute += nfc - nKeys;
-        s_off[c] = 1;
-        nNoMore++;
-      }
-    }
-    while (nToDistribute > 0 && nNoMore < nC) {
-      // nfeaturesCell + ceil((float)nToDistribute/(nCells-nNoMore))
-      int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nC - nNoMore));
-      nToDistribute = 0;
-      for (int c = 0; c < nC; c++) {
-        if (!s_off[c]) {
-          if (s_total[c] > nNew) {
-            s_retain[c] = nNew;
-          } else {
-            s_retain[c] = s_total[c];
-            nToDistribute += nNew - s_total[c];
-            s_off[c] = 1;
-            nNoMore++;
-          }
-        }
-      }
-    }
-    // kept counts and their offsets in the level list
-    int o = 0;
-    for (int c = 0; c < nC; c++) {
-      s_off[c] = o;
-      o += min(s_total[c], s_retain[c]);
-    }
-    s_off[nC] = o;
-    s_M = o;
-  }
-  __syncthreads();
-  SPROF(1);
-  const int M = s_M;
-  const bool list_lds = M <= SEL_LIST_CAP;
-  uint32_t* glist = lvl_scratch + (size_t)frame * P->cand_per_frame + L.cand_off;
-  // ---- per-cell retainBest, one wave per cell
-  {
-    lds_u32* buf = (lds_u32*)(s_buf_dyn + (size_t)wave * SEL_CELL_CAP);
-    for (int c = wave; c < nC; c += SEL_WAVES) {
-      const int n = s_total[c], keep = min(n, s_retain[c]), o = s_off[c];
-      if (keep <= 0) continue;
-      uint32_t* src = gcand + cg[c].cand_off;
-      if (n <= SEL_CELL_CAP) {
-        for (int i = lane; i < n; i += 64) buf[i] = src[i];
-        sdsel::wave_fence();
-        if (n > keep) sdsel::wave_nth_element(buf, n, keep, (sdsel::lds_u16*)s_tmp[wave]);
-        if (list_lds) {
-          for (int i = lane; i < keep; i += 64) s_list[o + i] = buf[i];
-        } else {
-          for (int i = lane; i < keep; i += 64) glist[o + i] = buf[i];
-        }
-        sdsel::wave_fence();   // buf is reused by this wave's next cell
-      }
-    }
-  }
-  __syncthreads();
-  // cells with more candidates than one wave's buffer (dense texture, large cells of big frames): wave 0, one cell at a
-  // time, with the buffers of all waves as one (SEL_WAVES x SEL_CELL_CAP entries); beyond that the serial replay in HBM
-  if (wave == 0) {
-    lds_u32* big = (lds_u32*)s_buf_dyn;
-    for (int c = 0; c < nC; c++) {
-      const int n = s_total[c], keep = min(n, s_retain[c]), o = s_off[c];
-      if (keep <= 0 || n <= SEL_CELL_CAP) continue;
-      uint32_t* src = gcand + cg[c].cand_off;
-      if (n <= SEL_WAVES * SEL_CELL_CAP) {
-        for (int i = lane; i < n; i += 64) big[i] = src[i];
-        sdsel::wave_fence();
-        if (n > keep) sdsel::wave_nth_element(big, n, keep, (sdsel::lds_u16*)s_tmp[0]);
-        if (list_lds) {
-          for (int i = lane; i < keep; i += 64) s_list[o + i] = big[i];
-        } else {
-          for (int i = lane; i < keep; i += 64) glist[o + i] = big[i];
-        }
-        sdsel::wave_fence();
-      } else {
-        if (lane == 0) {
-          if (n > keep) sdsel::nth_element(src, n, keep);
-          for (int i = 0; i < keep; i++) {
-            if (list_lds) s_list[o + i] = src[i];
-            else glist[o + i] = src[i];
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  SPROF(3);
-  // ---- level-wide retainBest
-  int Mout = M;
-  if (M > L.quota) {
-    if (list_lds) {
-      if (wave == 0) sdsel::wave_nth_element((lds_u32*)s_list, M, L.quota, (sdsel::lds_u16*)s_tmp[0]);
-    } else if (tid == 0) {
-      __threadfence_block();
-      sdsel::nth_element(glist, M, L.quota);
-    }
-    Mout = L.quota;
-  }
-  __syncthreads();
-  SPROF(5);
-  uint32_t* dst = sel + (size_t)frame * P->nsel + L.sel_off;
-  if (list_lds) {
-    for (int i = tid; i < Mout; i += 64 * SEL_WAVES) dst[i] = s_list[i];
-  } else {
-    for (int i = tid; i < Mout; i += 64 * SEL_WAVES) dst[i] = glist[i];
-  }
-  if (tid == 0) *out_n = Mout;
-  SPROF(6);
-}
-
 // ------------------------------------------------------------------------------------------
-// Split selection (the default): the same three steps as k_select_level, one launch each, so that no wave sits idle through
-// another step's serial part -- k_select_level keeps 8 waves resident per (level, frame) while ONE thread runs the quota loop
-// and ONE wave the level-wide retainBest, and gives a level with 30 cells 4 rounds of 8 waves.
 //   k_select_quota   one wave per frame, lane l runs level l's quota loop (counts staged through LDS); writes the kept count
 //                    and list offset of every cell and the list length of every level
 //   k_select_cells   one wave per (cell, frame): retainBest of the cell in LDS, survivors to their slot of the level list in
 //                    HBM; k_select_bigcells: the (rare) cells with more candidates than that kernel's small buffer
 //   k_select_final   one wave per (level, frame): level-wide retainBest (list through LDS), selected keys + count
-// Same helpers (introselect replay), same order of operations inside every step: results are identical to k_select_level's.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_select_quota(const OrbPlan* __restrict__ P, const CellGeom* __restrict__ cells,
                                                      const int32_t* __restrict__ cell_count, int32_t* __restrict__ cell_keep,
@@ -1483,7 +1302,8 @@ static int ensure_geometry(sd_orb* h, int w, int hgt) {
     set_error(std::string("unsupported geometry: ") + why);
     return SD_ERR_INVALID_ARG;   // the handle keeps its previous, still consistent geometry
   }
-  SD_REQUIRE(np.max_cells_per_level <= SEL_MAX_CELLS, SD_ERR_INVALID_ARG, "too many grid cells per level");
+  SD_REQUIRE(np.max_cells_per_level <= SEL_MAX_CELLS && (size_t)np.plan.ncells * 16 <= 60 * 1024, SD_ERR_INVALID_ARG,
+             "too many grid cells (k_select_quota keeps four ints per cell in LDS)");
   SD_HIP_CHECK(hipSetDevice(h->device));
   SD_HIP_CHECK(hipStreamSynchronize(h->stream));
   { int rcw = wait_trackers(h); if (rcw != SD_OK) return rcw; }
@@ -1572,13 +1392,11 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_fast_done, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[9], s));
   const int sel_cap = hp.max_cell_pixels > 12000 ? 1024 : 512;
-  const char* e_split = getenv("SD_SELECT_SPLIT");   // "0": the single-kernel variant (A/B, tests)
-  const bool sel_split = !(e_split && e_split[0] == '0');
-  if (sel_split && P.ncells > 0) {
+  if (P.ncells > 0) {
     hipLaunchKernelGGL(k_select_quota, dim3(n), dim3(64), (size_t)P.ncells * 16, s, h->d_plan, h->d_cells, h->d_cell_count, h->d_cell_keep,
                        h->d_cell_off, h->d_lvl_m);
     // small buffer = 2 x sel_cap entries (5 KB at VGA: 32 one-wave workgroups per CU; 4 x was 0.385 ms, 2 x and 1 x 0.275 ms);
-    // big buffer = what k_select_level had (SEL_WAVES x sel_cap)
+    // big buffer = SEL_WAVES x sel_cap
     int small_cap = 2 * sel_cap, big_cap = SEL_WAVES * sel_cap;
     if (const char* e = getenv("SD_SELECT_SMALLCAP")) small_cap = std::max(1, std::min(atoi(e), small_cap));   // tests: force the other paths
     if (const char* e = getenv("SD_SELECT_BIGCAP")) big_cap = std::max(small_cap, std::min(atoi(e), big_cap));
@@ -1587,9 +1405,6 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
     hipLaunchKernelGGL(k_select_bigcells, dim3(P.nlevels, n), dim3(64), (size_t)big_cap * 4 + 2 * WAVE_SEL_CAP * 2, s, h->d_plan, h->d_cells,
                        h->d_cand, h->d_cell_count, h->d_cell_keep, h->d_cell_off, h->d_scratch, small_cap, big_cap);
     hipLaunchKernelGGL(k_select_final, dim3(P.nlevels, n), dim3(64), 0, s, h->d_plan, h->d_lvl_m, h->d_scratch, h->d_sel, h->d_sel_count);
-  } else {
-    hipLaunchKernelGGL(k_select_level, dim3(P.nlevels, n), dim3(64 * SEL_WAVES), (size_t)SEL_WAVES * sel_cap * 4, s, h->d_plan, h->d_cells, h->d_cand,
-                       h->d_cell_count, h->d_scratch, h->d_sel, h->d_sel_count, sel_cap);
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[7], s));
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_blur_done, 0));
@@ -1705,10 +1520,10 @@ int orb_enable_double_buffer(sd_orb* h) {
 }  // namespace sd
 
 namespace sd {
-int read_sel_prof(unsigned long long* out64, int reset) {   // [0..55] select [level][slot<7], [56..63] FAST phases
+int read_sel_prof(unsigned long long* out64, int reset) {   // out64[8 * i + 7] = FAST phase i (the other slots: 0)
 #ifdef SD_PNP_PROF
   SD_HIP_CHECK(hipDeviceSynchronize());
-  SD_HIP_CHECK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_sel_prof), 64 * sizeof(unsigned long long)));
+  for (int i = 0; i < 64; i++) out64[i] = 0;   // the selection kernels carry no timers since the split (a rocprofv3 trace times them)
   unsigned long long f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   {
     std::vector<unsigned long long> wg((size_t)FPROF_FRAMES * FPROF_CELLS * 8);
@@ -1720,11 +1535,6 @@ int read_sel_prof(unsigned long long* out64, int reset) {   // [0..55] select [l
     }
   }
   for (int l = 0; l < 8; l++) out64[l * 8 + 7] = f[l];   // slot 7 of every level row carries FAST phase l
-  if (reset) {
-    unsigned long long z[64] = {};
-    SD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sel_prof), z, sizeof(z)));
-    SD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fast_prof), z, 8 * sizeof(unsigned long long)));
-  }
   return SD_OK;
 #else
   set_error("library built without -DSD_PNP_PROF");

@@ -64,7 +64,7 @@ struct HostPlan {
   std::vector<int> quota;
   size_t fast_lds_bytes;       // dynamic LDS of k_fast_cells (max over cells)
   int max_cells_per_level;
-  int max_cell_pixels;         // largest FAST detection zone (pixels): sizes k_select_level's per-wave buffers
+  int max_cell_pixels;         // largest FAST detection zone (pixels): sizes the selection kernels' LDS cell buffers
   double stage_bytes[8];       // algorithmic bytes per frame per stage
 };
 

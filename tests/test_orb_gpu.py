@@ -102,12 +102,11 @@ def test_edge_inputs(sd, oracle):
     ext.close()
 
 
-@pytest.mark.parametrize("env", [{"SD_SELECT_SMALLCAP": "48"}, {"SD_SELECT_SMALLCAP": "48", "SD_SELECT_BIGCAP": "160"},
-                                 {"SD_SELECT_SPLIT": "0"}])
+@pytest.mark.parametrize("env", [{"SD_SELECT_SMALLCAP": "48"}, {"SD_SELECT_SMALLCAP": "48", "SD_SELECT_BIGCAP": "160"}])
 def test_selection_paths(sd, oracle, env, monkeypatch):
     """The selection's rarely used paths give the same keys: cells larger than k_select_cells' buffer (trimmed by
-    k_select_bigcells in its LDS buffer), cells larger than that one too (serial replay in HBM), and the single-kernel
-    variant (SD_SELECT_SPLIT=0).  Textured frame and pure noise (densest lists, ties everywhere)."""
+    k_select_bigcells in its LDS buffer) and cells larger than that one too (serial replay in HBM).  Textured frame and pure
+    noise (densest lists, ties everywhere)."""
     for k_, v_ in env.items():
         monkeypatch.setenv(k_, v_)
     ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 1)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Stage cycle counters of k_select_level on the bench frames (library built with
-SD_EXTRA_FLAGS=-DSD_PNP_PROF).  Cycles of thread 0 per (level, stage), averaged per frame."""
+"""Phase cycle counters of k_fast_cells on the bench frames (library built with SD_EXTRA_FLAGS=-DSD_PNP_PROF, at most 256
+frames): cycles of thread 0 per phase, summed over a frame's cells.  (The selection kernels carried timers until they were
+split into k_select_quota / _cells / _bigcells / _final; a rocprofv3 kernel trace times those.)"""
 import ctypes as C
 import os
 import sys
@@ -24,11 +25,6 @@ for _ in range(reps):
     cur.extract_batch(frames)
 assert L.sd_debug_sel_prof(out, 1) == 0
 v = (np.array(list(out), np.float64) / (B * reps)).reshape(8, 8)
-names = ["load counts", "quota loop", "-", "per-cell retainBest", "-", "level retainBest", "write"]
-print("level " + " ".join(f"{n:>20s}" for n in names) + "        total")
-for l in range(8):
-    print(f"{l:5d} " + " ".join(f"{v[l, i]:20.0f}" for i in range(7)) + f" {v[l, :7].sum():12.0f}")
-print("sum   " + " ".join(f"{v[:, i].sum():20.0f}" for i in range(7)) + f" {v[:, :7].sum():12.0f}")
 fn = ["stage+clear", "A compass", "B1 ring test", "B2 scores", "(barrier)", "C nms+emit", "(barrier)"]
 print("k_fast_cells, cycles of thread 0 per frame (sum over the 148 cells):")
 v[:, 7] *= reps   # the FAST records are per workgroup and overwritten by every call: they hold ONE call, not `reps`
