@@ -912,6 +912,9 @@ __global__ __launch_bounds__(64) void k_select_final(const OrbPlan* __restrict__
 #define BLUR_RB 32                  // output rows per wave
 #define BLUR_TW 256                 // output columns per workgroup (64 lanes x 4)
 #define BLUR_TH (4 * BLUR_RB)       // output rows per workgroup (4 waves)
+#ifndef BLUR_PF
+#define BLUR_PF 6                   // input rows in flight per thread
+#endif
 
 __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, const BlurTile* __restrict__ tiles,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
@@ -937,11 +940,25 @@ __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, con
   const uint32_t T0 = 18u | 34u << 8 | 49u << 16 | 55u << 24, T1 = 49u | 34u << 8 | 18u << 16;
   const us2 T01 = {18, 34}, T23 = {49, 55}, T45 = {49, 34};
   uint32_t PP[6][4], prevR[4];
+  // Input rows are fetched BLUR_PF rows ahead of their use (the row index is clamped to the band's last input row instead of
+  // being branched around, so the loads are straight-line code): without this every row was load -> s_waitcnt vmcnt(0) ->
+  // compute, 38 dependent global round trips per wave.
+  uint32_t pf[BLUR_PF][3];
+  const int last_in = nrows + 5;
+  const uint32_t srow = (uint32_t)L.pstride;
+#pragma unroll
+  for (int d = 0; d < BLUR_PF; d++) {
+    const uint32_t* rp = (const uint32_t*)(src + (size_t)((uint32_t)min(d, last_in) * srow));
+    pf[d][0] = rp[0]; pf[d][1] = rp[1]; pf[d][2] = rp[2];
+  }
 #pragma unroll
   for (int r = 0; r < BLUR_RB + 6; r++) {
+    const uint32_t w0 = pf[r % BLUR_PF][0], w1 = pf[r % BLUR_PF][1], w2 = pf[r % BLUR_PF][2];
+    if (r + BLUR_PF < BLUR_RB + 6) {
+      const uint32_t* rp = (const uint32_t*)(src + (size_t)((uint32_t)min(r + BLUR_PF, last_in) * srow));
+      pf[r % BLUR_PF][0] = rp[0]; pf[r % BLUR_PF][1] = rp[1]; pf[r % BLUR_PF][2] = rp[2];
+    }
     if (r < nrows + 6) {
-      const uint32_t* rp = (const uint32_t*)(src + (size_t)r * L.pstride);
-      const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2];
       uint32_t R[4];
       R[0] = __builtin_amdgcn_udot4(w0, T0, __builtin_amdgcn_udot4(w1, T1, 0u, false), false);
 #pragma unroll
