@@ -1114,18 +1114,31 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
       dstep[q] = half ? -step[q] : step[q];
       colsum[q] = vsum[q] = 0;
     }
+    // All 2 x 16 row loads are issued first, unconditionally (every position of the 31 x 31 square around a keypoint lies
+    // inside the padded level; lane 31 / 63 reads column +16, also inside): straight-line code, 32 loads in flight.  With the
+    // disc test as a branch around each row the generated code was load -> s_waitcnt vmcnt(0) -> add, sixteen dependent
+    // round trips.  The disc is applied afterwards: umax[] is non-increasing, so row v counts iff v <= vlim(|u|).
+    int vals[16][DESC_KPW];
 #pragma unroll
-    for (int v = 0; v <= 15; v++) {   // fully unrolled: the 2 x 16 row loads are independent and issue back to back
-      if (act && au <= kUmax[v] && !(half && v == 0)) {
+    for (int v = 0; v <= 15; v++) {
 #pragma unroll
-        for (int q = 0; q < DESC_KPW; q++) {
-          const int val = pbase[q][off[q]];
-          colsum[q] += val;
-          vsum[q] += v * val;
-        }
+      for (int q = 0; q < DESC_KPW; q++) {
+        vals[v][q] = pbase[q][off[q]];
+        off[q] += (uint32_t)dstep[q];
       }
+    }
+    int vlim = -1;   // largest row index of this lane's column inside the disc (-1: lane outside)
 #pragma unroll
-      for (int q = 0; q < DESC_KPW; q++) off[q] += (uint32_t)dstep[q];
+    for (int v = 0; v <= 15; v++) vlim += (act && au <= kUmax[v]) ? 1 : 0;
+#pragma unroll
+    for (int v = 0; v <= 15; v++) {
+      const bool in = v <= vlim && !(half && v == 0);
+#pragma unroll
+      for (int q = 0; q < DESC_KPW; q++) {
+        const int val = in ? vals[v][q] : 0;
+        colsum[q] += val;
+        vsum[q] += v * val;
+      }
     }
 #pragma unroll
     for (int q = 0; q < DESC_KPW; q++) {   // DPP reduction of the device library
