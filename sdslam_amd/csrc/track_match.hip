@@ -104,22 +104,29 @@ __device__ __forceinline__ uint32_t match_window(float u, float v, float radius,
       const int e = e0 + lane;
       bool okc = false;
       int idx = 0;
+      unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
       if (e < b) {
         idx = S.s_key[e] & 2047;
-        const sd_keypoint kp = kps[idx];
+        // everything a candidate needs is fetched at once (position, octave, mvuRight, descriptor): one global round trip per
+        // candidate chunk instead of four dependent ones (the gates below used to sit between the loads)
+        const float kx = kps[idx].x, ky = kps[idx].y;
+        const int koct = kps[idx].octave;
+        const float ur2 = uright[idx];
+        if (MODE != 0) {
+          const unsigned long long* dk = (const unsigned long long*)(desc + (size_t)idx * 32);
+          k0 = dk[0]; k1 = dk[1]; k2 = dk[2]; k3 = dk[3];
+          asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3));   // keep the loads here (not sunk behind the gates)
+        }
         okc = true;
         if (bCheckLevels) {
-          if (kp.octave < minLevel) okc = false;
-          if (maxLevel >= 0 && kp.octave > maxLevel) okc = false;
+          if (koct < minLevel) okc = false;
+          if (maxLevel >= 0 && koct > maxLevel) okc = false;
         }
-        const float distx = kp.x - u, disty = kp.y - v;
+        const float distx = kx - u, disty = ky - v;
         if (!(fabsf(distx) < radius && fabsf(disty) < radius)) okc = false;
-        if (okc) {
-          const float ur2 = uright[idx];
-          if (ur2 > 0) {
-            const float er = fabsf(ur - ur2);
-            if (er > radius) okc = false;
-          }
+        if (okc && ur2 > 0) {
+          const float er = fabsf(ur - ur2);
+          if (er > radius) okc = false;
         }
         if (MODE == 2 && okc) {
           const int m = S.s_match[idx];
@@ -132,8 +139,7 @@ __device__ __forceinline__ uint32_t match_window(float u, float v, float radius,
       } else {
         uint32_t key = 0;
         if (okc) {
-          const unsigned long long* dk = (const unsigned long long*)(desc + (size_t)idx * 32);
-          const int dist = __popcll(dk[0] ^ d0) + __popcll(dk[1] ^ d1) + __popcll(dk[2] ^ d2) + __popcll(dk[3] ^ d3);
+          const int dist = __popcll(k0 ^ d0) + __popcll(k1 ^ d1) + __popcll(k2 ^ d2) + __popcll(k3 ^ d3);
           // NB: candidates failing the window test do not advance the reference's vIndices order
           // relative to each other, so the sorted-array position is a valid order key
           key = ((uint32_t)dist << 22) | ((uint32_t)(seq0 + (e - a)) << 11) | (uint32_t)idx;
@@ -201,6 +207,8 @@ __device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __rest
                                                 const float* __restrict__ sf, uint32_t* list, int lane, unsigned long long lt,
                                                 int* seq_total, unsigned long long gm = ~0ull) {
   const double xw = Xw[(size_t)i * 3], yw = Xw[(size_t)i * 3 + 1], zw = Xw[(size_t)i * 3 + 2];
+  int nLastOctave = l_oct[i];
+  asm volatile("" : "+v"(nLastOctave));   // fetched with the point, not after the frustum gates (one round trip less per point)
   const double X = (G.R[0][0] * xw + G.R[0][1] * yw + G.R[0][2] * zw) + G.t[0];
   const double Y = (G.R[1][0] * xw + G.R[1][1] * yw + G.R[1][2] * zw) + G.t[1];
   const double Z = (G.R[2][0] * xw + G.R[2][1] * yw + G.R[2][2] * zw) + G.t[2];
@@ -212,7 +220,6 @@ __device__ __forceinline__ uint32_t match_point(int i, const sd_keypoint* __rest
   const float v = cam.ffy * yc * invzc + cam.fcy;
   if (u < cam.min_x || u > cam.max_x) return MODE == 2 ? 0x7FFFFFFFu : 0;
   if (v < cam.min_y || v > cam.max_y) return MODE == 2 ? 0x7FFFFFFFu : 0;
-  const int nLastOctave = l_oct[i];
   const float radius = G.th * sf[nLastOctave];
   const int minLevel = G.bForward ? nLastOctave : (G.bBackward ? 0 : nLastOctave - 1);
   const int maxLevel = G.bForward ? -1 : (G.bBackward ? nLastOctave : nLastOctave + 1);
