@@ -26,8 +26,10 @@
 namespace sd {
 
 #define PNP_MAXN 2048   // = the tracker's keypoint capacity limit (sd_track_create)
+#ifndef PNP_CHUNK
 #define PNP_CHUNK 8    // RANSAC hypotheses evaluated side by side (typical runs accept within the first few);
                        // 3 lanes per hypothesis (one per EPnP beta variant)
+#endif
 #define PNP_WORDS (PNP_MAXN / 64)
 #define PNP_MAXSET 64   // largest RANSAC minimal set (mRansacMinSet) the general path draws
 
