@@ -542,11 +542,18 @@ extern "C" __device__ __attribute__((const)) int __ockl_wfred_add_i32(int);
 // 8 waves per SIMD: the kernel needed 65 VGPRs, one over the 64-register step; held to 64 it gains a resident wave per SIMD
 // and the whole extraction 5 % (169 k -> 177 k frames/s ORB-only)
 // Everything the workgroup needs besides its CellGeom arrives as kernel arguments (no dependent cell -> level -> plan loads):
-// img0 / frame_stride / pstride / edge describe the level's rows -- the padded pyramid level (edge = SD_EDGE), or, for level 0,
-// the caller's frames themselves (edge = 0; 4-byte aligned base and strides): FAST only touches interior pixels (the zones
-// start SD_EDGE - 3 px inside), so level 0 need not wait for the padded copy of the frame.
+// img0 / frame_stride / src / edge describe the levels' rows -- the padded pyramid (edge = SD_EDGE), or, for level 0, the
+// caller's frames themselves (edge = 0; 4-byte aligned base and strides): FAST only touches interior pixels (the zones
+// start SD_EDGE - 3 px inside), so level 0 need not wait for the padded copy of the frame.  One launch covers the cells
+// cell0 .. cell0 + gridDim.x - 1, of one level or of several consecutive ones (the small levels go together: each of their
+// launches was mostly ramp-up and tail).
+struct FastSrc {   // where the rows of a level start inside a frame's block, and their pitch (by value: one launch may span levels)
+  uint32_t off[SD_MAX_LEVELS];
+  int pstride[SD_MAX_LEVELS];
+};
+
 __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restrict__ cells, const uint8_t* __restrict__ img0,
-                                                    size_t frame_stride, int pstride, int edge, uint32_t* __restrict__ cand,
+                                                    size_t frame_stride, const FastSrc src, int edge, uint32_t* __restrict__ cand,
                                                     uint32_t cand_per_frame, int32_t* __restrict__ cell_count, int ncells_total,
                                                     int cell0, int th) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -559,7 +566,8 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
     if (tid == 0) cell_count[(size_t)frame * ncells_total + cell] = 0;
     return;
   }
-  const uint8_t* img = img0 + (size_t)frame * frame_stride;
+  const uint8_t* img = img0 + (size_t)frame * frame_stride + src.off[C.level];
+  const int pstride = src.pstride[C.level];
   uint32_t* out = cand + (size_t)frame * cand_per_frame + C.cand_off;
   const int zw = C.zw, zh = C.zh, S = C.strip_rows;
   const int xs = C.zx0 - 3 + edge;   // x of tile column 0 in the source rows (before alignment)
@@ -1371,9 +1379,23 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   if (fast0_direct) {
     if (prof) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
     fast_started = true;
-    hipLaunchKernelGGL(k_fast_cells, dim3(P.lv[0].ncells, n), dim3(256), hp.fast_lds_bytes, h->fast_stream, h->d_cells, d_imgs,
-                       frame_stride, stride, 0, h->d_cand, P.cand_per_frame, h->d_cell_count, P.ncells, P.lv[0].cell0, P.thFAST);
+    FastSrc fs0;
+    memset(&fs0, 0, sizeof(fs0));
+    fs0.pstride[0] = stride;
+    hipLaunchKernelGGL(k_fast_cells, dim3(P.lv[0].ncells, n), dim3(256), hp.fast_lds_level[0], h->fast_stream, h->d_cells, d_imgs,
+                       frame_stride, fs0, 0, h->d_cand, P.cand_per_frame, h->d_cell_count, P.ncells, P.lv[0].cell0, P.thFAST);
   }
+  FastSrc fsrc;
+  memset(&fsrc, 0, sizeof(fsrc));
+  for (int l = 0; l < P.nlevels; l++) {
+    fsrc.off[l] = P.lv[l].off;
+    fsrc.pstride[l] = P.lv[l].pstride;
+  }
+  // SD_FAST_MERGE_FROM (A/B): first level of the merged launch; >= nlevels = one launch per level.  Measured (1024 VGA frames,
+  // 8 levels): full step 163.1 k frames/s with one launch per level, 167.0 k from level 4, 169.8 k from level 3, 165.6 k from
+  // level 2 (ORB alone is indifferent up to 3 and loses from 2 on: the merged launch has to wait for the whole pyramid)
+  static const int merge_from_env = [] { const char* e = getenv("SD_FAST_MERGE_FROM"); return e ? atoi(e) : 3; }();
+  const int merge_from = std::max(1, merge_from_env);
   for (int l = 0; l < P.nlevels; l++) {
     const LevelGeom& L = P.lv[l];
     const LevelGeom& S = P.lv[l > 0 ? l - 1 : 0];
@@ -1395,14 +1417,28 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
                        h->d_pyr, wpr, magic((unsigned)wpr));
     }
     // FAST of this level starts now, on its own stream
-    if (L.ncells > 0 && !(l == 0 && fast0_direct)) {
+    // levels >= merge_from share ONE launch after the last level is complete (cells of consecutive levels are contiguous)
+    const bool merged = l >= merge_from;
+    int ncl = L.ncells;
+    size_t lds = hp.fast_lds_level[l];
+    if (merged) {
+      if (l != P.nlevels - 1) continue;
+      ncl = 0;
+      lds = 0;
+      for (int m = merge_from; m < P.nlevels; m++) {
+        ncl += P.lv[m].ncells;
+        lds = std::max(lds, hp.fast_lds_level[m]);
+      }
+    }
+    const int first = merged ? merge_from : l;
+    if (ncl > 0 && !(l == 0 && fast0_direct)) {
       SD_HIP_CHECK(hipEventRecord(h->ev_level[l], s));
       SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_level[l], 0));
       if (prof && !fast_started) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
       fast_started = true;
-      hipLaunchKernelGGL(k_fast_cells, dim3(L.ncells, n), dim3(256), hp.fast_lds_bytes, h->fast_stream, h->d_cells,
-                         (const uint8_t*)h->d_pyr + L.off, (size_t)P.pyr_frame_bytes, L.pstride, SD_EDGE, h->d_cand, P.cand_per_frame,
-                         h->d_cell_count, P.ncells, L.cell0, P.thFAST);
+      hipLaunchKernelGGL(k_fast_cells, dim3(ncl, n), dim3(256), lds, h->fast_stream, h->d_cells, (const uint8_t*)h->d_pyr,
+                         (size_t)P.pyr_frame_bytes, fsrc, SD_EDGE, h->d_cand, P.cand_per_frame, h->d_cell_count, P.ncells, P.lv[first].cell0,
+                         P.thFAST);
     }
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], s));

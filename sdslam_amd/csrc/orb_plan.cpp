@@ -85,6 +85,7 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
   int sel = 0;
   const float imageRatio = (float)w / h;   // src/ORBextractor.cc:469 (level 0 cols/rows)
   size_t lds_max = 0;
+  for (int l = 0; l < SD_MAX_LEVELS; l++) hp.fast_lds_level[l] = 0;
   double sum_px = 0, px0 = 0, px_last = 0;
 
   for (int l = 0; l < nlevels; l++) {
@@ -199,7 +200,11 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
               size_t need = tp * (S + 2 + 6) + sp * (S + 2 + 2) + 2 * 4 * rpw * c.zw + 64;
               static const size_t lds_kb = [] { const char* e = getenv("SD_FAST_LDS_KB"); return e ? (size_t)atoi(e) : (size_t)24; }();   // experiments; 24 KB measured best at 8 waves per SIMD (r2)
               bool fits = need <= lds_kb * 1024 && rpw * c.zw <= 4096 && (size_t)(S + 2) * c.zw < 65536;
-              if (fits || S == 1) { lds_max = std::max(lds_max, need); break; }
+              if (fits || S == 1) {
+                lds_max = std::max(lds_max, need);
+                hp.fast_lds_level[l] = std::max(hp.fast_lds_level[l], need);
+                break;
+              }
               S = std::max(1, S - std::max(1, S / 8));
             }
             c.strip_rows = S;

@@ -63,6 +63,8 @@ struct HostPlan {
   std::vector<float> sf, inv_sf, sigma2, inv_sigma2;
   std::vector<int> quota;
   size_t fast_lds_bytes;       // dynamic LDS of k_fast_cells (max over cells)
+  size_t fast_lds_level[SD_MAX_LEVELS];   // ... per level: the small levels' cells need far less than the budget, and a launch
+                                          // that asks for less LDS keeps more workgroups per CU
   int max_cells_per_level;
   int max_cell_pixels;         // largest FAST detection zone (pixels): sizes the selection kernels' LDS cell buffers
   double stage_bytes[8];       // algorithmic bytes per frame per stage
