@@ -124,13 +124,11 @@ __device__ __forceinline__ uint32_t pyr_px4(const LevelGeom& L, const LevelGeom&
     } else if (interior) {
       packed = ld_u32_unaligned(s + X0);
     } else {
+      uint32_t v[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        int x = px + k;
-        uint32_t v = 0;
-        if (x < L.w + 2 * SD_EDGE) v = s[reflect101(x - SD_EDGE, L.w)];
-        packed |= v << (8 * k);
-      }
+      for (int k = 0; k < 4; k++) v[k] = s[reflect101(min(px + k, L.w + 2 * SD_EDGE - 1) - SD_EDGE, L.w)];   // 4 loads in flight
+#pragma unroll
+      for (int k = 0; k < 4; k++) packed |= (px + k < L.w + 2 * SD_EDGE ? v[k] : 0u) << (8 * k);
     }
   } else {
     const uint8_t* sb = pyr + (size_t)frame * pyr_frame_bytes + S.off + (size_t)SD_EDGE * S.pstride + SD_EDGE;
@@ -148,16 +146,14 @@ __device__ __forceinline__ uint32_t pyr_px4(const LevelGeom& L, const LevelGeom&
           packed |= v << (8 * k);
         }
       } else {
+        uint32_t t[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          int x = px + k;
-          uint32_t v = 0;
-          if (x < L.w + 2 * SD_EDGE) {
-            int X = reflect101(x - SD_EDGE, L.w);
-            v = (r0[2 * X] + r0[2 * X + 1] + r1[2 * X] + r1[2 * X + 1] + 2) >> 2;
-          }
-          packed |= v << (8 * k);
+        for (int k = 0; k < 4; k++) {   // loads of the four pixels first (clamped column, result dropped beyond the padded row)
+          const int X = reflect101(min(px + k, L.w + 2 * SD_EDGE - 1) - SD_EDGE, L.w);
+          t[k] = r0[2 * X] + r0[2 * X + 1] + r1[2 * X] + r1[2 * X + 1];
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++) packed |= (px + k < L.w + 2 * SD_EDGE ? (t[k] + 2) >> 2 : 0u) << (8 * k);
       }
     } else {
       int sy0, b0, b1;
@@ -197,20 +193,24 @@ __device__ __forceinline__ uint32_t pyr_px4(const LevelGeom& L, const LevelGeom&
         }
       }
       if (!done) {
+        // border / edge pixels: the 4 x 4 source bytes are fetched first (columns beyond the padded row are clamped, their
+        // result is dropped), so a thread has 16 loads in flight instead of four dependent rounds of four
+        int p00[4], p01[4], p10[4], p11[4], a0[4], a1[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          int x = px + k;
-          uint32_t v = 0;
-          if (x < L.w + 2 * SD_EDGE) {
-            int X = reflect101(x - SD_EDGE, L.w);
-            int sx, a0, a1;
-            resize_coef(X, L.scale_x, S.w, true, &sx, &a0, &a1);
-            int sx1 = sx + 1 < S.w ? sx + 1 : S.w - 1;
-            int h0 = __mul24(r0[sx], a0) + __mul24(r0[sx1], a1);
-            int h1 = __mul24(r1[sx], a0) + __mul24(r1[sx1], a1);
-            int o = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
-            v = (uint32_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
-          }
+          const int x = min(px + k, L.w + 2 * SD_EDGE - 1);
+          const int X = reflect101(x - SD_EDGE, L.w);
+          int sx;
+          resize_coef(X, L.scale_x, S.w, true, &sx, &a0[k], &a1[k]);
+          const int sx1 = sx + 1 < S.w ? sx + 1 : S.w - 1;
+          p00[k] = r0[sx]; p01[k] = r0[sx1]; p10[k] = r1[sx]; p11[k] = r1[sx1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int h0 = __mul24(p00[k], a0[k]) + __mul24(p01[k], a1[k]);
+          const int h1 = __mul24(p10[k], a0[k]) + __mul24(p11[k], a1[k]);
+          const int o = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
+          const uint32_t v = px + k < L.w + 2 * SD_EDGE ? (uint32_t)(o < 0 ? 0 : (o > 255 ? 255 : o)) : 0u;
           packed |= v << (8 * k);
         }
       }
