@@ -1391,11 +1391,7 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
     fsrc.off[l] = P.lv[l].off;
     fsrc.pstride[l] = P.lv[l].pstride;
   }
-  // SD_FAST_MERGE_FROM (A/B): first level of the merged launch; >= nlevels = one launch per level.  Measured (1024 VGA frames,
-  // 8 levels): full step 163.1 k frames/s with one launch per level, 167.0 k from level 4, 169.8 k from level 3, 165.6 k from
-  // level 2 (ORB alone is indifferent up to 3 and loses from 2 on: the merged launch has to wait for the whole pyramid)
-  static const int merge_from_env = [] { const char* e = getenv("SD_FAST_MERGE_FROM"); return e ? atoi(e) : 3; }();
-  const int merge_from = std::max(1, merge_from_env);
+  const int merge_from = hp.fast_merge_from;   // orb_plan.cpp
   for (int l = 0; l < P.nlevels; l++) {
     const LevelGeom& L = P.lv[l];
     const LevelGeom& S = P.lv[l > 0 ? l - 1 : 0];

@@ -63,6 +63,7 @@ struct HostPlan {
   std::vector<float> sf, inv_sf, sigma2, inv_sigma2;
   std::vector<int> quota;
   size_t fast_lds_bytes;       // dynamic LDS of k_fast_cells (max over cells)
+  int fast_merge_from;         // levels >= this share one k_fast_cells launch (orb.hip); they keep the strip budget
   size_t fast_lds_level[SD_MAX_LEVELS];   // ... per level: the small levels' cells need far less than the budget, and a launch
                                           // that asks for less LDS keeps more workgroups per CU
   int max_cells_per_level;
