@@ -1215,9 +1215,16 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
   __shared__ unsigned long long s_best[PNP_WORDS], s_ref[PNP_WORDS];
   __shared__ int s_cnt[PNP_CHUNK];
   __shared__ double s_RtRef[12];
-  __shared__ double s_mtm[144], s_terms[64 * 9], s_red[64];
+  // One scratch area for two call-local uses (one wave per workgroup, the calls are sequential): the rows of M of the chunk's
+  // minimal sets inside epnp_minimal, and the ordered-sum terms / MtM / reduction slots inside epnp_refit_wave.  Keeping them
+  // apart cost 6 KB of the 30 KB this kernel holds per frame -- four frames per CU, beside k_fast_cells workgroups of 24-39 KB.
+  constexpr int kScrMrows = PNP_CHUNK * 4 * 24, kScrRefit = 64 * 9 + 144 + 64;
+  __shared__ double s_scr[kScrMrows > kScrRefit ? kScrMrows : kScrRefit];
+  double* const s_Mrows = s_scr;
+  double* const s_terms = s_scr;
+  double* const s_mtm = s_scr + 64 * 9;
+  double* const s_red = s_scr + 64 * 9 + 144;
   __shared__ int s_modp[PNP_MAXSET], s_modv[PNP_MAXSET], s_draw[PNP_MAXSET];   // general minimal sets (mRansacMinSet != 4)
-  __shared__ double s_Mrows[PNP_CHUNK * 4 * 24];   // rows of M of the chunk's minimal sets (epnp_minimal)
   const int lane = threadIdx.x;
   // persistent waves: the grid may be smaller than the batch (launch_pnp)
   for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
