@@ -30,7 +30,9 @@ namespace sd {
 
 #define MT_MAXKP 2048      // keypoints per frame supported by the 11-bit index fields
 #define MT_WAVES 8
+#ifndef MT_LIST_CAP
 #define MT_LIST_CAP 4096   // candidate keys per frame kept in LDS (more: per-point slow path)
+#endif
 #define GRID_COLS 64
 #define GRID_ROWS 48
 #define TH_HIGH 100
