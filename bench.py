@@ -184,7 +184,7 @@ def cpu_baseline(scenes, lasts, T0s, rs, pose_solver="pnp", locals_=None, budget
 
 
 # ------------------------------------------------------------------------------------------------ PMC / VALU figures
-STAGE_KERNELS = {"pyramid": ["k_pyr_split", "k_pyr_resize", "k_pyr_edges", "k_pyr_rows", "k_pyr_level"], "fast_nms": ["k_fast_cells"],
+STAGE_KERNELS = {"pyramid": ["k_pyr_resize", "k_pyr_edges", "k_pyr_rows", "k_pyr_level", "k_pyr_fused"], "fast_nms": ["k_fast_cells"],
                  "select": ["k_select_quota", "k_select_cells", "k_select_bigcells", "k_select_final", "k_select_level"], "blur": ["k_blur"], "orient_desc": ["k_orient_desc"], "image_align": ["k_align"],
                  "search_by_projection": ["k_match"], "pnp_ransac": ["k_pnp"], "search_by_points": ["k_search_points"]}
 PMC_FRAMES = 1024       # frames per launch in the committed PMC passes (tools/run_profiles.sh: default batch)
