@@ -333,8 +333,16 @@ static int wait_inputs(sd_track* h, bool need_ref, bool pyramid_only = false) {
   // ImageAlign reads pyramids only: it may start as soon as the current batch's pyramid exists, beside FAST / selection /
   // descriptors of the same batch (SD_ALIGN_EARLY=0 restores the wait for the whole extraction)
   static const bool early = !(getenv("SD_ALIGN_EARLY") && getenv("SD_ALIGN_EARLY")[0] == '0');
-  if (h->cur->extract_recorded)
-    SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, (pyramid_only && early && h->cur->pyr_event_live) ? h->cur->ev_pyr_done : h->cur->ev_extract_done, 0));
+  // ... but not beside FAST: k_align holds 30 KB of LDS per frame (4 frames per CU), FAST wants 24-39 KB per workgroup, while
+  // selection + descriptors, which follow FAST, use next to none.  Waiting for the end of the batch's FAST launches instead of
+  // its pyramid: full step 175.2 -> 178.8 k frames/s (three alternating runs; k_align 1.38 -> 0.84 ms in the pipeline).
+  // SD_ALIGN_AFTER_FAST=0: wait for the pyramid only.
+  static const bool after_fast = !(getenv("SD_ALIGN_AFTER_FAST") && getenv("SD_ALIGN_AFTER_FAST")[0] == '0');
+  if (h->cur->extract_recorded) {
+    hipEvent_t ev = h->cur->ev_extract_done;
+    if (pyramid_only && early && h->cur->pyr_event_live) ev = after_fast ? h->cur->ev_fast_done : h->cur->ev_pyr_done;
+    SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, ev, 0));
+  }
   if (need_ref && h->ref->extract_recorded) SD_HIP_CHECK(hipStreamWaitEvent(h->pnp_stream, h->ref->ev_extract_done, 0));
   return SD_OK;
 }
