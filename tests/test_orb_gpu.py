@@ -137,6 +137,27 @@ def test_odd_geometries_all_stages(sd, oracle, shape, cfg):
     ext.close()
 
 
+@pytest.mark.parametrize("shape,cfg", [((480, 752), (1000, 1.2, 8, 20)), ((376, 1241), (2000, 1.2, 8, 20)), ((240, 320), (500, 1.2, 8, 20)),
+                                       ((1080, 1920), (2000, 1.2, 8, 20)), ((600, 800), (1500, 1.3, 6, 15)),
+                                       ((480, 640), (1000, 1.1, 12, 20)), ((97, 131), (200, 1.2, 4, 20))])
+def test_more_geometries(sd, oracle, shape, cfg):
+    """EuRoC / KITTI / QVGA / 1080p / other pyramids (12 levels, 1.3x) / a tiny frame: keypoints and descriptors of two frames per
+    geometry equal the oracle's.  Exercises what depends on the plan: FAST launches per level vs the merged small levels, whole-cell
+    vs strip staging, level-0 FAST straight from the frames, the selection's per-geometry buffers."""
+    H, W = shape
+    base = make_image(77)
+    img = np.ascontiguousarray(np.tile(base, (3, 3))[:H, :W]) if (H > 480 or W > 640) else np.ascontiguousarray(base[:H, :W])
+    frames = np.stack([img, img[::-1].copy()])
+    ext = sd.ORBextractor(*cfg, W, H, 2)
+    ora = oracle.OrbOracle(*cfg)
+    k, d, n = ext.extract_batch(frames)
+    for i in range(2):
+        ok, od = ora.extract(frames[i])
+        assert n[i] == len(ok) and len(ok) > 100
+        assert np.array_equal(k[i, :n[i]], ok) and np.array_equal(d[i, :n[i]], od)
+    ext.close()
+
+
 def test_errors_are_loud(sd):
     ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 1)
     with pytest.raises(sd.SdError):
