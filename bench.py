@@ -133,9 +133,18 @@ def cpu_loop(scenes, lasts, T0s, rs, budget_s, pose_solver="pnp", locals_=None, 
     return np.array(rows)
 
 
+def parse_pyramid(txt):
+    """'8x1.2' -> (1000, 1.2, 8, 20): levels x scale factor; '5x2.0' is the reference's own default (src/Config.cc:48-51)."""
+    nl, sf = txt.lower().split("x")
+    return (1000, float(sf), int(nl), 20)
+
+
 def cpu_worker_main(argv):
-    """`bench.py --cpu-worker SEED BUDGET POSE_SOLVER`: one independent frame stream on one core (the all-cores leg)."""
+    """`bench.py --cpu-worker SEED BUDGET POSE_SOLVER PYRAMID`: one independent frame stream on one core (the all-cores leg)."""
+    global CFG
     seed, budget, solver = int(argv[0]), float(argv[1]), argv[2]
+    if len(argv) > 3:
+        CFG = parse_pyramid(argv[3])
     from oracle import oracle as O
     from sdslam_amd import synth
     scenes = make_cases(1, seed)
@@ -148,7 +157,7 @@ def cpu_worker_main(argv):
     if solver == "track":
         oc = O.OrbOracle(*CFG, fast_build=True)
         ck, cd = oc.extract(scenes[0]["cur"])
-        loc = [{k: v[:1000] for k, v in synth.local_map_case(500, ck, cd, scenes[0]["T_cur"]).items()}]
+        loc = [{k: v[:1000] for k, v in synth.local_map_case(500, ck, cd, scenes[0]["T_cur"], scale_factor=CFG[1], nlevels=CFG[2]).items()}]
     t0 = time.perf_counter()
     rows = cpu_loop(scenes, lasts, T0, rs, budget, solver if solver != "hamming" else "pnp", loc, max_frames=100000, warm=1)
     print(json.dumps({"frames": len(rows), "busy_s": float(rows.sum() / 1e3), "wall_s": time.perf_counter() - t0}))
@@ -159,8 +168,8 @@ def cpu_baseline(scenes, lasts, T0s, rs, pose_solver="pnp", locals_=None, budget
     per_frame = rows.sum(axis=1)
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     nwork = max(1, min(ncores, 16))      # a 1-GPU box's CPU share is 16 cores whatever the host shows
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(3000 + i), str(budget_all), pose_solver],
-                              stdout=subprocess.PIPE, text=True) for i in range(nwork)]
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(3000 + i), str(budget_all), pose_solver,
+                               f"{CFG[2]}x{CFG[1]}"], stdout=subprocess.PIPE, text=True) for i in range(nwork)]
     outs = []
     for p in procs:
         o, _ = p.communicate(timeout=600)
@@ -273,7 +282,7 @@ class Workload:
         self.locals_u = None
         if pose_solver == "track" and not orb_only:        # the local map of every frame (UpdateLocalMap is the caller's)
             ck, cd, cn = self.cur.extract_batch(np.stack([s_["cur"] for s_ in scenes[:nu]]))
-            self.locals_u = [{k: v[:1000] for k, v in synth.local_map_case(500 + i, ck[i, :cn[i]], cd[i, :cn[i]], scenes[i]["T_cur"]).items()}
+            self.locals_u = [{k: v[:1000] for k, v in synth.local_map_case(500 + i, ck[i, :cn[i]], cd[i, :cn[i]], scenes[i]["T_cur"], scale_factor=CFG[1], nlevels=CFG[2]).items()}
                              for i in range(nu)]
             self.trk.set_local(0, [self.locals_u[i] for i in self.idx])
         if hamming:
@@ -431,6 +440,8 @@ def main():
     ap.add_argument("--orb-only", action="store_true", help="time ORB extraction alone (configs[1] without matching)")
     ap.add_argument("--hamming", action="store_true", help="BASELINE configs[1]: ORB extract + brute-force Hamming match "
                                                             "(ORBmatcher::SearchByPoints, 1000 x 1000 per frame pair)")
+    ap.add_argument("--pyramid", default="8x1.2", help="LEVELSxSCALE: 8x1.2 = BASELINE configs[1]/[3] (the metric); 5x2.0 = the reference's own "
+                                                       "default pyramid (src/Config.cc:48-51), reported beside it")
     ap.add_argument("--res", default="640x480", help="frame size WxH (BASELINE configs[4] uses 1280x720 frames; the metric is quoted at 640x480)")
     ap.add_argument("--pose-solver", choices=["pnp", "poseopt", "motion_model", "track"], default="pnp",
                     help="pnp: PnPsolver RANSAC (the BASELINE metric); poseopt: Optimizer::PoseOptimization, the pose solve the reference's "
@@ -445,7 +456,9 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world} (launch one rank per GPU, or run without a launcher)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    global W, H, BOUNDS
+    global W, H, BOUNDS, CFG
+    CFG = parse_pyramid(args.pyramid)
+    pyr_txt = f"{CFG[2]}-level x{CFG[1]:g}"
     W, H = (int(v) for v in args.res.lower().split("x"))
     BOUNDS = (0.0, float(W), 0.0, float(H))
     B = args.batch
@@ -561,12 +574,13 @@ def main():
         traffic, valu = pmc_for_stage(names[dom], B)
         terr = float(np.mean([np.abs(al["T"][b][:3, 3] - scenes[wl.idx[b]]["T_cur"][:3, 3]).max() for b in range(min(B, nu))]))
         if args.orb_only:
-            workload = f"ORB extract only (BASELINE configs[1] without matching), {W}x{H}"
+            workload = f"ORB extract only (BASELINE configs[1] without matching), {W}x{H}, {pyr_txt}"
         elif args.hamming:
-            workload = (f"BASELINE configs[1]: {W}x{H} 8-level x1.2 pyramid, 1000 kp, ORB extract + brute-force Hamming match "
+            workload = (f"BASELINE configs[1]: {W}x{H} {pyr_txt} pyramid, 1000 kp, ORB extract + brute-force Hamming match "
                         "(ORBmatcher::SearchByPoints, 1000 x 1000 per frame pair, nnratio 0.75, orientation check)")
         else:
-            workload = (f"BASELINE configs[3] at the configs[1] pyramid: {W}x{H}, 8-level x1.2, 1000 kp; ORB extract + ImageAlign (levels 4,3,2) + "
+            which = "BASELINE configs[3] at the configs[1] pyramid" if CFG[2:0:-1] == (8, 1.2) else "BASELINE configs[3] at the reference's default pyramid (src/Config.cc:48-51)"
+            workload = (f"{which}: {W}x{H}, {pyr_txt}, 1000 kp; ORB extract + ImageAlign (levels 4,3,2) + "
                         "SearchByProjection + " + ("PnP RANSAC (maxIts 200; iterations actually run: tracking.mean_pnp_iterations)"
                                                    if args.pose_solver == "pnp" else "Optimizer::PoseOptimization (g2o LM, 4x10 its)") +
                         (", as one Tracking::TrackWithMotionModel call" if args.pose_solver in ("motion_model", "track") else "") +
@@ -576,7 +590,7 @@ def main():
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload, "pose_solver": args.pose_solver,
+            "config": {"workload": workload, "pose_solver": args.pose_solver, "pyramid": args.pyramid,
                        "frames_per_gpu_per_step": B, "unique_scenes": nu, "inputs": "resident in HBM", "timed_region_s": dt,
                        "pose_records": ("REHEARSAL ONLY (SD_BENCH_REHEARSAL): all ranks on one GPU, gloo over host memory -- not a measurement" if rehearsal else
                                         "all-gathered over RCCL every step inside the timed region, straight from the device buffer the "

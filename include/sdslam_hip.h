@@ -28,6 +28,29 @@ const char* sd_last_error(void);      /* thread-local description of the last fa
 int sd_device_count(void);            /* number of visible HIP devices (0 on a CPU box)    */
 const char* sd_version(void);
 
+/* Process-wide options: the library's tuning and test switches.  The library never reads the environment.  Integer values;
+ * unknown names and out-of-range values fail with SD_ERR_INVALID_ARG.  "plan" options are read when a handle (re)builds its
+ * geometry (first extraction at a new frame size), "create" options when a handle is created, the others at every call.
+ *   extract.fast0_from_frames  1     0: FAST of level 0 reads the padded pyramid copy instead of the caller's frames
+ *   extract.use_graph          0     1: replay the extraction pipeline as a captured hipGraph (slower on ROCm 7.2; kept for tests)
+ *   extract.select_small_cap   0     >0: cap (entries) of the per-cell selection buffer -- tests force the large-cell paths
+ *   extract.select_big_cap     0     >0: cap of the per-level selection buffer -- tests force the serial fallback
+ *   extract.fast_merge_from    3     plan: first pyramid level of the merged FAST launch (>= nlevels: one launch per level)
+ *   extract.fast_lds_kb        24    plan: LDS budget of a FAST strip
+ *   extract.fast_lds_whole_kb  40    plan: LDS budget under which a cell of the unmerged levels is processed as one strip
+ *   track.stream_priority      2     create: priority of the tracking stream, 0 lowest / 1 normal / 2 highest
+ *   track.align_start          2     ImageAlign of a batch may start 0: after its whole extraction, 1: after its pyramid,
+ *                                    2: after its pyramid and FAST launches (beside selection + descriptors)
+ *   track.align_min_waves      5     register budget of k_align in waves per SIMD (3, 4, 5)
+ *   track.bf_list_k            4     SearchByPoints: keys kept per point, 1..4 -- tests force the whole-row recomputation
+ *   track.pnp_grid_cap         0     >0: k_pnp walks the frames with at most this many workgroups
+ *   track.poseopt_waves        0     k_pose_opt waves per frame: 0 = by batch size (4 up to 256 frames, else 1), 1, 4
+ * Results never depend on an option (each setting is covered by a parity test); only speed does. */
+int sd_set_option(const char* name, int value);
+int sd_get_option(const char* name, int* value);
+int sd_option_count(void);
+const char* sd_option_name(int index);
+
 /* cv::KeyPoint, 28 bytes: {pt.x, pt.y, size, angle, response, octave, class_id} */
 typedef struct sd_keypoint {
   float x, y, size, angle, response;
@@ -248,9 +271,13 @@ int sd_track_get_point_matches(sd_track* h, int frame0, int n_frames, int32_t* m
 int sd_track_align(sd_track* h, int n_frames, int mode);
 int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori);
 /* sd_track_pnp = PnPsolver(CurrentFrame, CurrentFrame.mvpMapPoints) + SetRansacParameters(...) + iterate(n_iterations)
- * (src/PnPsolver.cc:71-244); min_set 4 is the reference's default (src/PnPsolver.h:74), 1..64 are accepted.
+ * (src/PnPsolver.cc:71-244); min_set 4 is the reference's default (src/PnPsolver.h:74); 3..64 are accepted (1 and 2: SD_ERR_INVALID_ARG --
+ * EPnP on fewer than 3 points is pinned by nothing; 3 is pinned only as "no hypothesis is ever accepted").
  * sd_track_pnp_iterate = a further iterate(n_iterations) on those solvers: mnIterations, the best hypothesis so far and the
- * position in the rand() stream carry over (src/PnPsolver.cc:177).  Each RANSAC iteration consumes min_set values of the
+ * position in the rand() stream carry over (src/PnPsolver.cc:177).  The reference's solver owns copies of its inputs; here they
+ * stay in the tracker, so anything that replaces them -- a new extraction on `cur`, sd_track_match / _with_motion_model /
+ * _relocalize, sd_track_set_matches / _set_last / _set_rand -- ends the solvers' life: the next sd_track_pnp_iterate fails with
+ * SD_ERR_INVALID_ARG until sd_track_pnp constructs new ones.  Each RANSAC iteration consumes min_set values of the
  * stream given to sd_track_set_rand; a call that could run past the supplied values fails with SD_ERR_INVALID_ARG.
  * sd_track_set_matches replaces CurrentFrame.mvpMapPoints of the slots by the caller's vector (indices into the
  * last-frame arrays, -1 = NULL; cap entries per frame, the rest NULL): PnPsolver and Optimizer::PoseOptimization take any

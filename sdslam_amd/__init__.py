@@ -7,6 +7,7 @@ works anywhere (so the symbol table can be checked), but every compute entry poi
 loudly when the library or a GPU is missing.
 """
 from .capi import (KP_DTYPE, SdError, lib, lib_path, ORBextractor, Tracker, DeviceBuffer, device_count,  # noqa: F401
-                   hamming, plan_info)
+                   hamming, plan_info, set_option, get_option, option_names, options)
 
-__all__ = ["KP_DTYPE", "SdError", "lib", "lib_path", "ORBextractor", "Tracker", "DeviceBuffer", "device_count", "hamming", "plan_info"]
+__all__ = ["KP_DTYPE", "SdError", "lib", "lib_path", "ORBextractor", "Tracker", "DeviceBuffer", "device_count", "hamming", "plan_info",
+           "set_option", "get_option", "option_names", "options"]

@@ -75,6 +75,10 @@ def lib():
         L.sd_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.sd_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.sd_hamming.argtypes = [C.c_void_p, C.c_void_p]
+        L.sd_set_option.argtypes = [C.c_char_p, C.c_int]
+        L.sd_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+        L.sd_option_name.restype = C.c_char_p
+        L.sd_option_name.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -86,6 +90,40 @@ def _check(rc):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def set_option(name: str, value: int):
+    """sd_set_option: process-wide tuning / test switch (include/sdslam_hip.h lists them; the library reads no environment)."""
+    _check(lib().sd_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    _check(lib().sd_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+def option_names():
+    L = lib()
+    return [L.sd_option_name(i).decode() for i in range(L.sd_option_count())]
+
+
+class options:
+    """with options({"extract.use_graph": 1}): ... -- set for the block, restore afterwards."""
+
+    def __init__(self, values):
+        self.values, self.saved = dict(values), {}
+
+    def __enter__(self):
+        for k, v in self.values.items():
+            self.saved[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            set_option(k, v)
+        return False
 
 
 def device_count() -> int:

@@ -1375,7 +1375,7 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_fast_done, 0));
   const bool src_aligned = (((uintptr_t)d_imgs | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) == 0;
   // FAST of level 0 reads the frames themselves when they are 4-byte aligned: it starts at once, beside the resize chain
-  const bool fast0_direct = src_aligned && P.lv[0].ncells > 0 && getenv("SD_FAST0_PYR") == nullptr;
+  const bool fast0_direct = src_aligned && P.lv[0].ncells > 0 && opt(OPT_FAST0_FROM_FRAMES) != 0;
   if (fast0_direct) {
     if (prof) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
     fast_started = true;
@@ -1450,6 +1450,10 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
     if (!fast_started) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
     SD_HIP_CHECK(hipEventRecord(ev[2], h->fast_stream));
   }
+  // ev_fast_done stands for "pyramid AND FAST complete" (a tracker's ImageAlign waits for it alone, track.hip wait_inputs): a
+  // level without grid cells launches no FAST, so the FAST stream has not necessarily waited for that level's resize
+  // (few features: no cells at all on the merged small levels) -- order it behind the whole pyramid explicitly
+  SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_pyr_done, 0));
   SD_HIP_CHECK(hipEventRecord(h->ev_fast_done, h->fast_stream));
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_fast_done, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[9], s));
@@ -1460,14 +1464,16 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
     // small buffer = 2 x sel_cap entries (5 KB at VGA: 32 one-wave workgroups per CU; 4 x was 0.385 ms, 2 x and 1 x 0.275 ms);
     // big buffer = SEL_WAVES x sel_cap
     int small_cap = 2 * sel_cap, big_cap = SEL_WAVES * sel_cap;
-    if (const char* e = getenv("SD_SELECT_SMALLCAP")) small_cap = std::max(1, std::min(atoi(e), small_cap));   // tests: force the other paths
-    if (const char* e = getenv("SD_SELECT_BIGCAP")) big_cap = std::max(small_cap, std::min(atoi(e), big_cap));
+    if (const int e = opt(OPT_SELECT_SMALL_CAP)) small_cap = std::max(1, std::min(e, small_cap));   // tests: force the other paths
+    if (const int e = opt(OPT_SELECT_BIG_CAP)) big_cap = std::max(small_cap, std::min(e, big_cap));
     hipLaunchKernelGGL(k_select_cells, dim3(P.ncells, n), dim3(64), (size_t)small_cap * 4 + 2 * WAVE_SEL_CAP * 2, s, h->d_plan, h->d_cells,
                        h->d_cand, h->d_cell_count, h->d_cell_keep, h->d_cell_off, h->d_scratch, small_cap);
     hipLaunchKernelGGL(k_select_bigcells, dim3(P.nlevels, n), dim3(64), (size_t)big_cap * 4 + 2 * WAVE_SEL_CAP * 2, s, h->d_plan, h->d_cells,
                        h->d_cand, h->d_cell_count, h->d_cell_keep, h->d_cell_off, h->d_scratch, small_cap, big_cap);
-    hipLaunchKernelGGL(k_select_final, dim3(P.nlevels, n), dim3(64), 0, s, h->d_plan, h->d_lvl_m, h->d_scratch, h->d_sel, h->d_sel_count);
   }
+  // (also without any grid cell -- nfeatures so small that every level's levelCols is 0: the per-level counts the descriptor
+  // kernel reads must still be written, as zeros)
+  hipLaunchKernelGGL(k_select_final, dim3(P.nlevels, n), dim3(64), 0, s, h->d_plan, h->d_lvl_m, h->d_scratch, h->d_sel, h->d_sel_count);
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[7], s));
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_blur_done, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[4], s));
@@ -1505,9 +1511,9 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
     SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_set_free[h->set], 0));
     h->set_busy[h->set] = false;
   }
-  // hipGraph replay is opt-in (SD_USE_GRAPH=1): measured on ROCm 7.2 / MI355X the single-frame call takes 0.43 ms through
+  // hipGraph replay is opt-in (option "extract.use_graph"): measured on ROCm 7.2 / MI355X the single-frame call takes 0.43 ms through
   // the graph against 0.37 ms with direct launches (tools/exp_pcie.py), so direct launches stay the default
-  static const bool use_graph = getenv("SD_USE_GRAPH") != nullptr;
+  const bool use_graph = opt(OPT_USE_GRAPH) != 0;
   int rc = SD_OK;
   if (prof || !use_graph) {
     rc = pipeline_body(h, d_imgs, n, stride, frame_stride, prof, ev);
@@ -1551,6 +1557,7 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   h->pyr_event_live = prof || !use_graph;
   SD_HIP_CHECK(hipEventRecord(h->ev_extract_done, s));
   h->extract_recorded = true;
+  h->extract_serial++;
   if (prof) h->ev_calls++;
   h->last_frames = n;
   return SD_OK;

@@ -40,6 +40,7 @@ struct sd_orb {
   bool set_busy[2] = {false, false};
   hipEvent_t ev_extract_done = nullptr;   // end of the most recent extraction on `stream`
   bool extract_recorded = false;
+  unsigned long long extract_serial = 0;  // extractions launched so far (a tracker checks that its inputs have not been replaced)
   bool pyr_event_live = false;            // ev_pyr_done of the most recent extraction is a real record (not a captured graph node)
   // device buffers
   sd::OrbPlan* d_plan = nullptr;
@@ -66,7 +67,7 @@ struct sd_orb {
   int32_t* d_nout = nullptr;
   size_t cap_pyr = 0, cap_cand = 0, cap_cells = 0, cap_tiles = 0, cap_coef = 0;
   // hipGraph cache of the extraction pipeline (multi-stream fork/join captured once per argument set); opt-in with
-  // SD_USE_GRAPH=1 -- see launch_pipeline for the measurement that keeps direct launches the default
+  // option "extract.use_graph" -- see launch_pipeline for the measurement that keeps direct launches the default
   struct GraphEntry {
     const void* imgs = nullptr;
     int n = 0, stride = 0, set = -1;

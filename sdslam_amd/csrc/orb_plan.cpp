@@ -1,5 +1,6 @@
 // See orb_plan.h.  Pure host code (no HIP).
 #include "orb_plan.h"
+#include "sd_common.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -86,11 +87,10 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
   const float imageRatio = (float)w / h;   // src/ORBextractor.cc:469 (level 0 cols/rows)
   size_t lds_max = 0;
   {
-    // SD_FAST_MERGE_FROM (A/B): first level of the merged FAST launch; >= nlevels = one launch per level.  Measured (1024 VGA
+    // option "extract.fast_merge_from" (A/B): first level of the merged FAST launch; >= nlevels = one launch per level.  Measured (1024 VGA
     // frames, 8 levels): full step 163.1 k frames/s with one launch per level, 167.0 k from level 4, 169.8 k from level 3,
     // 165.6 k from level 2 (ORB alone is indifferent up to 3 and loses from 2 on: the merged launch waits for the whole pyramid)
-    const char* e = getenv("SD_FAST_MERGE_FROM");
-    hp.fast_merge_from = std::max(1, e ? atoi(e) : 3);
+    hp.fast_merge_from = std::max(1, opt(OPT_FAST_MERGE_FROM));
   }
   for (int l = 0; l < SD_MAX_LEVELS; l++) hp.fast_lds_level[l] = 0;
   double sum_px = 0, px0 = 0, px_last = 0;
@@ -203,13 +203,9 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
             // Budgets (r2, measured): a cell that fits in one strip within 40 KB is done in one strip (no second staging /
             // barrier round: VGA ORB-only 220 k -> 231 k frames/s, full step 168.6 k -> 173.5 k); cells that need strips
             // anyway (1280x720: 311 x 98 pixels) get 24 KB strips (720p 81.2 k vs 79.9 k at 40 KB, 57.7 k at 60 KB).
-            // SD_FAST_LDS_KB / SD_FAST_LDS_WHOLE_KB override the two (experiments).
-            static const size_t lds_kb = [] { const char* e = getenv("SD_FAST_LDS_KB"); return e ? (size_t)atoi(e) : (size_t)24; }();
-            static const size_t whole_kb = [] {
-              const char* e = getenv("SD_FAST_LDS_WHOLE_KB");
-              const char* e2 = getenv("SD_FAST_LDS_KB");
-              return e ? (size_t)atoi(e) : (e2 ? (size_t)atoi(e2) : (size_t)40);
-            }();
+            // Options "extract.fast_lds_kb" / "extract.fast_lds_whole_kb" override the two (experiments).
+            const size_t lds_kb = (size_t)opt(OPT_FAST_LDS_KB);
+            const size_t whole_kb = (size_t)opt(OPT_FAST_LDS_WHOLE_KB);
             int S = c.zh;
             // (levels of the merged launch keep the strip budget: a launch asks for the LARGEST need of its cells, and one
             // 34-KB level would take every small cell of that launch from 6 to 4 workgroups per CU -- 720p: 81.3 k -> 77.7 k)

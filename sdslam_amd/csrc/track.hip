@@ -29,7 +29,8 @@ struct sd_track {
   int max_points = 0, max_batch = 0, kp_cap = 0, device = 0;
   int rand_per_frame = 0;
   std::vector<int> rand_len;      // rand() values actually supplied per slot (sd_track_set_rand)
-  bool have_pnp = false;          // sd_track_pnp has constructed the solvers sd_track_pnp_iterate continues
+  bool have_pnp = false;          // sd_track_pnp has constructed the solvers sd_track_pnp_iterate continues ...
+  unsigned long long pnp_serial = 0;   // ... on the keypoints of THIS extraction of `cur` (the reference's solver owns copies of its inputs)
   PnpParams pnp_params{};
   int pnp_frames = 0, pnp_iter_upper = 0;   // slots / upper bound of mnIterations of those solvers
   TrackBuffers tb{};
@@ -231,8 +232,8 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
       // 146.1 k).  Default: highest.
       int lo = 0, hi = 0;
       e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-      const char* pe = getenv("SD_TRACK_PRIO");   // experiments: "low" | "normal" | default high
-      const int prio = (pe && pe[0] == 'l') ? lo : ((pe && pe[0] == 'n') ? (lo + hi) / 2 : hi);
+      const int pe = opt(OPT_TRACK_PRIORITY);   // option "track.stream_priority": 0 low | 1 normal | 2 high (default)
+      const int prio = pe == 0 ? lo : (pe == 1 ? (lo + hi) / 2 : hi);
       if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->pnp_stream, hipStreamNonBlocking, prio);
     }
     if (e != hipSuccess) {
@@ -287,6 +288,7 @@ int sd_track_set_last(sd_track* h, int frame0, int n_frames, const int32_t* n_la
                       const uint8_t* desc, const int32_t* octave, const float* angle, const int32_t* obs) {
   TRACK_RANGE(h, frame0, n_frames);
   SD_REQUIRE(n_last && valid && Xw && desc && octave && angle && obs, SD_ERR_INVALID_ARG, "NULL argument");
+  h->have_pnp = false;   // the solvers' 3-D points are being replaced
   const size_t M = h->max_points, o = (size_t)frame0;
   for (int f = 0; f < n_frames; f++) SD_REQUIRE(n_last[f] >= 0 && n_last[f] <= h->max_points, SD_ERR_CAPACITY, "n_last exceeds max_points");
   // the octave indexes mvScaleFactors / mvLevelSigma2 on the device (search radius, level window)
@@ -321,6 +323,7 @@ int sd_track_set_poses(sd_track* h, int frame0, int n_frames, const double* Tref
 int sd_track_set_rand(sd_track* h, int frame0, int n_frames, const int32_t* rand_values, int per_frame) {
   TRACK_RANGE(h, frame0, n_frames);
   SD_REQUIRE(rand_values && per_frame >= 1 && per_frame <= h->rand_per_frame, SD_ERR_INVALID_ARG, "bad rand stream");
+  h->have_pnp = false;   // a resumed iterate() continues at a position of the OLD stream
   SD_HIP_CHECK(hipMemcpy2DAsync(h->tb.rand_stream + (size_t)frame0 * h->rand_per_frame, (size_t)h->rand_per_frame * 4, rand_values,
                                 (size_t)per_frame * 4, (size_t)per_frame * 4, n_frames, hipMemcpyHostToDevice, h->cur->stream));
   SD_HIP_CHECK(hipStreamSynchronize(h->cur->stream));
@@ -331,13 +334,14 @@ int sd_track_set_rand(sd_track* h, int frame0, int n_frames, const int32_t* rand
 // Order the tracking stream behind the extractions it consumes ...
 static int wait_inputs(sd_track* h, bool need_ref, bool pyramid_only = false) {
   // ImageAlign reads pyramids only: it may start as soon as the current batch's pyramid exists, beside FAST / selection /
-  // descriptors of the same batch (SD_ALIGN_EARLY=0 restores the wait for the whole extraction)
-  static const bool early = !(getenv("SD_ALIGN_EARLY") && getenv("SD_ALIGN_EARLY")[0] == '0');
+  // descriptors of the same batch (option "track.align_start" = 0 restores the wait for the whole extraction)
+  const int align_start = opt(OPT_ALIGN_START);
+  const bool early = align_start != 0;
   // ... but not beside FAST: k_align holds 30 KB of LDS per frame (4 frames per CU), FAST wants 24-39 KB per workgroup, while
   // selection + descriptors, which follow FAST, use next to none.  Waiting for the end of the batch's FAST launches instead of
   // its pyramid: full step 175.2 -> 178.8 k frames/s (three alternating runs; k_align 1.38 -> 0.84 ms in the pipeline).
-  // SD_ALIGN_AFTER_FAST=0: wait for the pyramid only.
-  static const bool after_fast = !(getenv("SD_ALIGN_AFTER_FAST") && getenv("SD_ALIGN_AFTER_FAST")[0] == '0');
+  // "track.align_start" = 1: wait for the pyramid only; 2 (default): for the FAST launches.
+  const bool after_fast = align_start == 2;
   if (h->cur->extract_recorded) {
     hipEvent_t ev = h->cur->ev_extract_done;
     if (pyramid_only && early && h->cur->pyr_event_live) ev = after_fast ? h->cur->ev_fast_done : h->cur->ev_pyr_done;
@@ -402,6 +406,7 @@ int sd_track_match(sd_track* h, int n_frames, float th, int mono, int check_ori)
   int rc = check_ready(h, n_frames);
   if (rc != SD_OK) return rc;
   hipStream_t s = h->pnp_stream;
+  h->have_pnp = false;   // mvpMapPoints is rewritten: solvers built on the old vector cannot be continued
   rc = wait_inputs(h, false);
   if (rc != SD_OK) return rc;
   hipEvent_t* ev = h->ev[h->ev_calls[1] % sd_track::kRing];
@@ -506,6 +511,7 @@ int sd_track_with_motion_model(sd_track* h, int n_frames, int align_mode, float 
   SD_REQUIRE(min_matches >= 3 && min_inliers >= 0, SD_ERR_INVALID_ARG, "bad gates (reference: 20 matches, 10 inliers)");
   hipStream_t s = h->pnp_stream;
   const TrackBuffers& tb = h->tb;
+  h->have_pnp = false;
   const bool use_ref = align_mode >= 0;
   if (use_ref)
     SD_REQUIRE(h->ref->have_geom && h->ref->last_frames >= n_frames && h->ref->cur_w == h->cur->cur_w && h->ref->cur_h == h->cur->cur_h,
@@ -779,6 +785,7 @@ int sd_track_get_point_matches(sd_track* h, int frame0, int n_frames, int32_t* m
 int sd_track_set_matches(sd_track* h, int frame0, int n_frames, const int32_t* cur_match, int cap) {
   TRACK_RANGE(h, frame0, n_frames);
   SD_REQUIRE(cur_match && cap >= 1 && cap <= h->kp_cap, SD_ERR_INVALID_ARG, "bad match array (cap must be 1..keypoint capacity)");
+  h->have_pnp = false;   // the saved best-inlier mask indexes the old correspondence list
   std::vector<int32_t> full((size_t)n_frames * h->kp_cap, -1), cnt((size_t)n_frames, 0);
   for (int f = 0; f < n_frames; f++)
     for (int i = 0; i < cap; i++) {
@@ -820,8 +827,12 @@ int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers,
                  float th2, int n_iterations) {
   int rc = check_ready(h, n_frames);
   if (rc != SD_OK) return rc;
-  // the reference's default is 4 (src/PnPsolver.h:74); other sizes go through the general (one hypothesis at a time) path
-  SD_REQUIRE(min_set >= 1 && min_set <= 64, SD_ERR_INVALID_ARG, "minSet must be in [1, 64]");
+  // the reference's default is 4 (src/PnPsolver.h:74); other sizes go through the general (one hypothesis at a time) path.
+  // Fewer than 4 correspondences leave EPnP's 12 x 12 system rank deficient beyond its 4-D null space: the reference's own
+  // hypotheses are then rounding noise of its summation order.  minSet 3 is accepted because its OUTCOME is pinned against
+  // the oracle (no hypothesis reaches minInliers: empty Mat + bNoMore, tests/pnp_cases.py "minset3_degenerate"); 1 and 2
+  // are pinned by nothing and refused.
+  SD_REQUIRE(min_set >= 3 && min_set <= 64, SD_ERR_INVALID_ARG, "minSet must be in [3, 64]");
   SD_REQUIRE(max_iterations >= 1 && n_iterations >= 0 && min_inliers >= 0, SD_ERR_INVALID_ARG, "bad RANSAC parameters");
   const long long upper = std::max(max_iterations, n_iterations);
   rc = check_rand(h, n_frames, (long long)min_set * upper);
@@ -839,6 +850,7 @@ int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers,
   rc = run_pnp(h, n_frames, pp);
   if (rc == SD_OK) {
     h->have_pnp = true;
+    h->pnp_serial = h->cur->extract_serial;
     h->pnp_params = pp;
     h->pnp_frames = n_frames;
     h->pnp_iter_upper = (int)upper;
@@ -853,7 +865,10 @@ int sd_track_pnp(sd_track* h, int n_frames, double probability, int min_inliers,
 int sd_track_pnp_iterate(sd_track* h, int n_frames, int n_iterations) {
   int rc = check_ready(h, n_frames);
   if (rc != SD_OK) return rc;
-  SD_REQUIRE(h->have_pnp && n_frames <= h->pnp_frames, SD_ERR_INVALID_ARG, "sd_track_pnp has not constructed solvers for these slots");
+  SD_REQUIRE(h->have_pnp && n_frames <= h->pnp_frames, SD_ERR_INVALID_ARG,
+             "sd_track_pnp has not constructed solvers for these slots (or their matches / map points / rand stream were replaced since)");
+  SD_REQUIRE(h->pnp_serial == h->cur->extract_serial, SD_ERR_INVALID_ARG,
+             "the current frames were re-extracted since sd_track_pnp: the solvers' keypoints are gone");
   SD_REQUIRE(n_iterations >= 0, SD_ERR_INVALID_ARG, "bad n_iterations");
   PnpParams pp = h->pnp_params;
   const long long upper = std::max<long long>(pp.max_iterations, (long long)h->pnp_iter_upper + n_iterations);

@@ -243,9 +243,6 @@ __device__ __noinline__ double solve_and_exp(ldsd* H, const ldsd* b, ldsd* x, ld
 // runs the float chi2 chain while lane 0 of wave 1 solves the 6 x 6 system and prepares the candidate update, so the
 // LDLT + exp latency hides under the chain; thread 0 takes the accept / stop decisions and forms the next trial pose.
 #define AL_PT_THREADS 320
-#ifndef AL_DEFAULT_MINW
-#define AL_DEFAULT_MINW 5
-#endif
 #define AL_PT_WAVES (AL_PT_THREADS / 64)
 static_assert(AL_PT_THREADS >= AL_MAXP, "one thread per point");
 
@@ -700,8 +697,8 @@ int read_align_prof(unsigned long long* out16, int reset) {
 int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sf,
                  const float* d_sf, int n_frames, int mode, hipStream_t s) {
   const int grid = n_frames;
-  // register budget: 5 waves per SIMD = four workgroups per CU (1024 frames resident at once); SD_ALIGN_MINW=3|4 for experiments
-  static const int minw = [] { const char* e = getenv("SD_ALIGN_MINW"); return e ? atoi(e) : AL_DEFAULT_MINW; }();
+  // register budget: 5 waves per SIMD = four workgroups per CU (1024 frames resident at once); option "track.align_min_waves" = 3 | 4 for experiments
+  const int minw = opt(OPT_ALIGN_MIN_WAVES);
   if (minw == 3)
     hipLaunchKernelGGL(k_align<3>, dim3(grid), dim3(AL_PT_THREADS), 0, s, cur->d_plan, cur->d_pyr, ref->d_pyr, tb, cam, d_inv_sf, d_sf, mode, n_frames);
   else if (minw == 4)

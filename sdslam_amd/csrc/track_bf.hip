@@ -266,10 +266,9 @@ int launch_search_points(const sd_orb* cur, const sd_orb* ref, const TrackBuffer
                          hipStream_t s) {
   const int capw = (tb.kp_cap + 63) & ~63;
   SD_REQUIRE(capw <= 2048, SD_ERR_CAPACITY, "SearchByPoints supports at most 2048 keypoints per keyframe");
-  // SD_BF_K=1..3 (tests): phase 2 sees only the first keys of every list, so the whole-wave recomputation -- rare on real
+  // option "track.bf_list_k" = 1..3 (tests): phase 2 sees only the first keys of every list, so the whole-wave recomputation -- rare on real
   // data -- runs for most points
-  const char* ek = getenv("SD_BF_K");
-  const int klist = ek ? std::min(BF_K, std::max(1, atoi(ek))) : BF_K;
+  const int klist = std::min(BF_K, std::max(1, opt(OPT_BF_LIST_K)));
   const size_t lds = (size_t)BF_TILE * 32 + (size_t)capw * BF_K * 4 + (size_t)capw * 2 * 2 + (size_t)(capw >> 5) * 4 * 2 + 8 + 33 * 4 + 16;
   hipLaunchKernelGGL(k_search_points, dim3(n_frames), dim3(BF_THREADS), lds, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_desc,
                      cur->d_nout, (ref->have_dist ? ref->d_kps_un : ref->d_kps), ref->d_desc, ref->d_nout, tb, nnratio, check_ori, capw, klist);

@@ -1606,7 +1606,7 @@ int read_pnp_prof(unsigned long long* out32, int reset) {
 
 int launch_pnp(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sigma2, const PnpParams& pp,
                int n_frames, hipStream_t s) {
-  static const int grid_cap = [] { const char* e = getenv("SD_PNP_GRID"); return e ? atoi(e) : 0; }();
+  const int grid_cap = opt(OPT_PNP_GRID_CAP);   // option "track.pnp_grid_cap" (experiments): frames are walked by a capped grid
   const int grid = grid_cap > 0 ? std::min(n_frames, grid_cap) : n_frames;
   hipLaunchKernelGGL(k_pnp, dim3(grid), dim3(64), 0, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam, d_sigma2, pp,
                      n_frames);

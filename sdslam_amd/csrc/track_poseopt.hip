@@ -723,8 +723,8 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
 
 int launch_pose_opt(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sigma2, int source, int n_frames,
                     hipStream_t s, int min_matches, int min_inliers) {
-  // waves per frame by batch size: SD_POSEOPT_WAVES=1|4 overrides (experiments)
-  static const int forced = getenv("SD_POSEOPT_WAVES") ? atoi(getenv("SD_POSEOPT_WAVES")) : 0;
+  // waves per frame by batch size: option "track.poseopt_waves" = 1 | 4 overrides (tests, experiments)
+  const int forced = opt(OPT_POSEOPT_WAVES);
   const int waves = forced ? forced : (n_frames <= 256 ? 4 : 1);
   const sd_keypoint* kps = cur->have_dist ? cur->d_kps_un : cur->d_kps;
   if (waves == 4)

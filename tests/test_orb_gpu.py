@@ -102,22 +102,21 @@ def test_edge_inputs(sd, oracle):
     ext.close()
 
 
-@pytest.mark.parametrize("env", [{"SD_SELECT_SMALLCAP": "48"}, {"SD_SELECT_SMALLCAP": "48", "SD_SELECT_BIGCAP": "160"}])
-def test_selection_paths(sd, oracle, env, monkeypatch):
+@pytest.mark.parametrize("opts", [{"extract.select_small_cap": 48}, {"extract.select_small_cap": 48, "extract.select_big_cap": 160}])
+def test_selection_paths(sd, oracle, opts):
     """The selection's rarely used paths give the same keys: cells larger than k_select_cells' buffer (trimmed by
     k_select_bigcells in its LDS buffer) and cells larger than that one too (serial replay in HBM).  Textured frame and pure
     noise (densest lists, ties everywhere)."""
-    for k_, v_ in env.items():
-        monkeypatch.setenv(k_, v_)
-    ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 1)
-    ora = oracle.OrbOracle(1000, 1.2, 8, 20)
-    rng = np.random.default_rng(5)
-    for img in (make_image(61), rng.integers(0, 256, size=(480, 640)).astype(np.uint8)):
-        k, d = ext(img)
-        ok, od = _compare_frame(oracle, ext, ora, img, 0, 8)
-        assert len(ok) > 500
-        assert np.array_equal(k, ok) and np.array_equal(d, od)
-    ext.close()
+    with sd.options(opts):
+        ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 1)
+        ora = oracle.OrbOracle(1000, 1.2, 8, 20)
+        rng = np.random.default_rng(5)
+        for img in (make_image(61), rng.integers(0, 256, size=(480, 640)).astype(np.uint8)):
+            k, d = ext(img)
+            ok, od = _compare_frame(oracle, ext, ora, img, 0, 8)
+            assert len(ok) > 500
+            assert np.array_equal(k, ok) and np.array_equal(d, od)
+        ext.close()
 
 
 @pytest.mark.parametrize("shape,cfg", [((479, 637), (1000, 1.2, 8, 20)), ((242, 321), (500, 1.2, 6, 20)),
@@ -194,33 +193,26 @@ def test_undistort_keypoints_bit_exact(sd, oracle):
 
 
 def test_hipgraph_replay_matches_direct_launches(sd, oracle):
-    """SD_USE_GRAPH=1 (captured multi-stream pipeline replayed as one hipGraph): same bits as direct launches, on
-    first capture and on replays, after a geometry change and with a second argument set."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import numpy as np, sys
-sys.path.insert(0, %r)
-import sdslam_amd
-from sdslam_amd.synth import make_image
-from oracle import oracle
-ext = sdslam_amd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2)
-ora = oracle.OrbOracle(1000, 1.2, 8, 20)
-imgs = np.stack([make_image(3), make_image(4)])
-exp = [ora.extract(im) for im in imgs]
-for rep in range(3):                       # capture, replay, replay
-    k, d, n = ext.extract_batch(imgs)
+    """Option "extract.use_graph" (captured multi-stream pipeline replayed as one hipGraph): same bits as direct launches, on
+    first capture and on replays, after a geometry change, with a second argument set, and when the option is switched
+    off again on the same handle."""
+    ora = oracle.OrbOracle(1000, 1.2, 8, 20)
+    imgs = np.stack([make_image(3), make_image(4)])
+    exp = [ora.extract(im) for im in imgs]
+    ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2)
+    with sd.options({"extract.use_graph": 1}):
+        for rep in range(3):                       # capture, replay, replay
+            k, d, n = ext.extract_batch(imgs)
+            for i in range(2):
+                assert np.array_equal(k[i, :n[i]], exp[i][0]) and np.array_equal(d[i, :n[i]], exp[i][1]), (rep, i)
+        small = make_image(5)[:240, :320].copy()    # geometry change drops the graphs
+        ks, ds = ext(small)
+        es = oracle.OrbOracle(1000, 1.2, 8, 20).extract(small)
+        assert np.array_equal(ks, es[0]) and np.array_equal(ds, es[1])
+        k, d, n = ext.extract_batch(imgs[:1])       # different batch size: new capture
+        assert np.array_equal(k[0, :n[0]], exp[0][0])
+    assert sd.get_option("extract.use_graph") == 0
+    k, d, n = ext.extract_batch(imgs)               # direct launches again
     for i in range(2):
-        assert np.array_equal(k[i, :n[i]], exp[i][0]) and np.array_equal(d[i, :n[i]], exp[i][1]), (rep, i)
-small = make_image(5)[:240, :320].copy()    # geometry change drops the graphs
-ks, ds = ext(small)
-es = oracle.OrbOracle(1000, 1.2, 8, 20).extract(small)
-assert np.array_equal(ks, es[0]) and np.array_equal(ds, es[1])
-k, d, n = ext.extract_batch(imgs[:1])       # different batch size: new capture
-assert np.array_equal(k[0, :n[0]], exp[0][0])
-print("graph ok")
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SD_USE_GRAPH="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
-    assert r.returncode == 0 and "graph ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        assert np.array_equal(k[i, :n[i]], exp[i][0]) and np.array_equal(d[i, :n[i]], exp[i][1])
+    ext.close()

@@ -90,47 +90,38 @@ def test_invalid_octave_is_refused(sd):
     trk.set_last(0, [last])
 
 
-CHILD = r'''
-import os, sys, numpy as np
-sys.path.insert(0, ROOT)
-import sdslam_amd
-from sdslam_amd import synth
-from sdslam_amd.capi import DeviceBuffer
-K = (synth.FX, synth.FY, synth.CX, synth.CY)
-s = [synth.make_scene(20 + i) for i in range(2)]
-cur, ref = sdslam_amd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2), sdslam_amd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2)
-rk, rd, rn = ref.extract_batch(np.stack([x["ref"] for x in s]))
-trk = sdslam_amd.Tracker(cur, ref, 1000, 2, 200)
-trk.set_camera(*K, 0.0, (0.0, 640.0, 0.0, 480.0))
-trk.set_last(0, [synth.tracking_case(i, rk[i, :rn[i]], rd[i, :rn[i]]) for i in range(2)])
-trk.set_poses(0, [x["T_ref"] for x in s], [synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04)) @ x["T_cur"] for x in s])
-trk.set_rand(0, np.tile(synth.glibc_rand_stream(800), (2, 1)))
-fr = np.stack([x["cur"] for x in s])
-d = DeviceBuffer(fr.nbytes); d.upload(fr)
-for _ in range(3):                      # replayed graph from the second call on
-    cur.extract_batch_device(d.ptr, 2, 640, 480)
-    trk.align(2, 0); trk.match(2, 8.0, True, True); trk.pnp(2, 0.99, 10, 200, 4, 0.28, 5.991, 200)
-al, (cm, nm), pn = trk.get_align(0, 2), trk.get_matches(0, 2), trk.get_pnp(0, 2)
-np.savez(sys.argv[1], T=np.stack(al["T"]), iters=al["iters"], cm=cm, nm=nm, pT=pn["T"], inl=pn["inliers"])
-'''
-
-
-def test_tracker_behind_graph_replayed_extraction(tmp_path):
-    """SD_USE_GRAPH=1: inside a captured graph the pyramid-done event is a graph node, not an event record; the tracker's
-    early start (ImageAlign right behind the pyramid) must then wait for the whole extraction.  Fresh child processes (the
-    switch is read once): identical results with and without the graph."""
+def test_tracker_behind_graph_replayed_extraction(sd):
+    """Option "extract.use_graph": inside a captured graph the pyramid-done event is a graph node, not an event record; the
+    tracker's early start (ImageAlign right behind the pyramid / the FAST launches) must then wait for the whole
+    extraction.  Identical results with and without the graph."""
+    from sdslam_amd.capi import DeviceBuffer
+    s = [synth.make_scene(20 + i) for i in range(2)]
+    fr = np.stack([x["cur"] for x in s])
+    d = DeviceBuffer(fr.nbytes)
+    d.upload(fr)
     outs = []
-    for flag in ("0", "1"):
-        out = tmp_path / f"g{flag}.npz"
-        env = dict(os.environ)
-        env.pop("SD_USE_GRAPH", None)
-        if flag == "1":
-            env["SD_USE_GRAPH"] = "1"
-        r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + CHILD, str(out)], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-3000:]
-        outs.append(np.load(out))
-    for k in outs[0].files:
+    for flag in (0, 1):
+        with sd.options({"extract.use_graph": flag}):
+            cur, ref = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2), sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2)
+            rk, rd, rn = ref.extract_batch(np.stack([x["ref"] for x in s]))
+            trk = sd.Tracker(cur, ref, 1000, 2, 200)
+            trk.set_camera(*K, 0.0, BOUNDS)
+            trk.set_last(0, [synth.tracking_case(i, rk[i, :rn[i]], rd[i, :rn[i]]) for i in range(2)])
+            trk.set_poses(0, [x["T_ref"] for x in s], [synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04)) @ x["T_cur"] for x in s])
+            trk.set_rand(0, np.tile(synth.glibc_rand_stream(800), (2, 1)))
+            for _ in range(3):                      # replayed graph from the second call on
+                cur.extract_batch_device(d.ptr, 2, 640, 480)
+                trk.align(2, 0)
+                trk.match(2, 8.0, True, True)
+                trk.pnp(2, 0.99, 10, 200, 4, 0.28, 5.991, 200)
+            al, (cm, nm), pn = trk.get_align(0, 2), trk.get_matches(0, 2), trk.get_pnp(0, 2)
+            outs.append(dict(T=np.stack(al["T"]), iters=al["iters"].copy(), cm=cm.copy(), nm=nm.copy(), pT=pn["T"].copy(), inl=pn["inliers"].copy()))
+            trk.close()
+            cur.close()
+            ref.close()
+    for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert outs[0]["nm"].min() > 50
 
 
 def test_cpp_frame_overloads_run_the_motion_model_body(sd, oracle, tmp_path):

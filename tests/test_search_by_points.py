@@ -1,7 +1,7 @@
 """ORBmatcher::SearchByPoints (reference src/ORBmatcher.cc:1209-1301): brute-force Hamming between two keyframes' map
 points.  CPU: the oracle against an independent numpy statement of the loop.  GPU: k_search_points vs the oracle on scene
 pairs, on near-duplicate (tiled) images where the greedy vbMatched2 exclusion matters, with the order-dependent fallback
-forced (SD_BF_K), and the direct read-out of the device grid (Frame::GetFeaturesInArea) vs oracle.features_in_area."""
+forced (option "track.bf_list_k"), and the direct read-out of the device grid (Frame::GetFeaturesInArea) vs oracle.features_in_area."""
 import os
 
 import numpy as np
@@ -109,14 +109,13 @@ def bf_rig(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("klist", [None, "1", "2"])
+@pytest.mark.parametrize("klist", [None, 1, 2])
 def test_hip_search_by_points_matches_oracle(oracle, bf_rig, klist):
     r, B, trk = bf_rig, bf_rig["B"], bf_rig["trk"]
     cap = r["k1"].shape[1]
     rng = np.random.default_rng(9)
-    old = os.environ.get("SD_BF_K")
-    if klist:
-        os.environ["SD_BF_K"] = klist
+    import sdslam_amd
+    sdslam_amd.set_option("track.bf_list_k", klist or 4)
     try:
         for flags in ("all", "random"):
             h1 = np.ones((B, cap), np.uint8) if flags == "all" else (rng.random((B, cap)) > 0.3).astype(np.uint8)
@@ -136,10 +135,7 @@ def test_hip_search_by_points_matches_oracle(oracle, bf_rig, klist):
                         tot += n
                     assert tot > 100      # the comparison is not vacuous
     finally:
-        if old is None:
-            os.environ.pop("SD_BF_K", None)
-        else:
-            os.environ["SD_BF_K"] = old
+        sdslam_amd.set_option("track.bf_list_k", 4)
 
 
 @pytest.mark.gpu

@@ -9,6 +9,10 @@ from sdslam_amd import synth
 pytestmark = pytest.mark.gpu
 K = (synth.FX, synth.FY, synth.CX, synth.CY)
 CFG = (1000, 1.2, 8, 20)
+# both pyramids of SURVEY D3: "p8" = BASELINE's 8 levels x 1.2, "p5" = the reference's own default, 5 levels x 2.0
+# (src/Config.cc:48-51): ImageAlign then works on 40x30 / 80x60 / 160x120 images (src/ImageAlign.cc:36-39,57,382) and the
+# search radius / octave window on scale factors 2^n (src/ORBmatcher.cc:999-1004)
+CFGS = {"p8": CFG, "p5": (1000, 2.0, 5, 20)}
 BOUNDS = (0.0, 640.0, 0.0, 480.0)
 POSE_TOL = 1e-5
 
@@ -21,9 +25,11 @@ def sd():
     return sdslam_amd
 
 
-@pytest.fixture(scope="module")
-def rig(sd, oracle):
-    """4 scenes with different motions; extractors + oracle state for each."""
+@pytest.fixture(scope="module", params=["p8", "p5"])
+def rig(sd, oracle, request):
+    """4 scenes with different motions; extractors + oracle state for each; once per pyramid."""
+    CFG = CFGS[request.param]
+    NL = CFG[2]
     motions = [((0.02, -0.01, 0.015), (0.4, -0.3, 0.5)), ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0)),
                ((-0.03, 0.02, -0.01), (-0.6, 0.2, 0.3)), ((0.01, 0.03, 0.02), (0.2, 0.5, -0.8))]
     B = len(motions)
@@ -43,12 +49,15 @@ def rig(sd, oracle):
     trk = sd.Tracker(cur, ref, max_points=1000, max_batch=B, pnp_max_iterations=300)
     trk.set_camera(*K, 0.0, BOUNDS)
     trk.set_last(0, [o["last"] for o in oras])
-    return dict(B=B, scenes=scenes, cur=cur, ref=ref, trk=trk, oras=oras)
+    yield dict(B=B, scenes=scenes, cur=cur, ref=ref, trk=trk, oras=oras, cfg=CFG, NL=NL, name=request.param)
+    trk.close()
+    cur.close()
+    ref.close()
 
 
 def _oracle_align(oracle, o, s, T0, mode=0):
-    pc = [o["oc"].level(l) for l in range(8)]
-    pr = [o["orf"].level(l) for l in range(8)]
+    pc = [o["oc"].level(l) for l in range(len(o["tab"]["sf"]))]
+    pr = [o["orf"].level(l) for l in range(len(o["tab"]["sf"]))]
     Xw = o["last"]["Xw"][o["last"]["valid"] != 0]
     return oracle.align(pc, pr, o["tab"]["inv_sf"], o["tab"]["sf"], Xw, s["T_ref"], T0, K, mode=mode)
 
@@ -67,7 +76,7 @@ def test_image_align_matches_oracle(sd, oracle, rig, init):
         r = _oracle_align(oracle, rig["oras"][i], rig["scenes"][i], T0[i])
         assert g["ok"][i] == r["ok"]
         assert np.abs(g["T"][i] - r["T"]).max() <= POSE_TOL, (i, np.abs(g["T"][i] - r["T"]).max())
-        assert np.array_equal(g["iters"][i][:8], r["iters"]), (i, g["iters"][i][:8], r["iters"])
+        assert np.array_equal(g["iters"][i][:len(r["iters"])], r["iters"]), (i, g["iters"][i][:len(r["iters"])], r["iters"])
         assert abs(g["error"][i] - r["error"]) <= 1e-7 * max(1.0, abs(r["error"]))
         assert abs(g["chi2"][i] - r["chi2"]) <= 1e-9 * max(1.0, abs(r["chi2"]))
 
@@ -81,12 +90,12 @@ def test_image_align_modes(sd, oracle, rig):
         g = trk.get_align(0, B)
         for i in range(B):
             o = rig["oras"][i]
-            pc = [o["oc"].level(l) for l in range(8)]
-            pr = [o["orf"].level(l) for l in range(8)]
+            pc = [o["oc"].level(l) for l in range(rig["NL"])]
+            pr = [o["orf"].level(l) for l in range(rig["NL"])]
             Xw = o["last"]["Xw"][o["last"]["valid"] != 0]
             r = oracle.align(pc, pr, o["tab"]["inv_sf"], o["tab"]["sf"], Xw, rig["scenes"][i]["T_ref"], T0[i], K, mode=mode)
             assert g["ok"][i] == r["ok"], (mode, i)
-            assert np.array_equal(g["iters"][i][:8], r["iters"])
+            assert np.array_equal(g["iters"][i][:len(r["iters"])], r["iters"])
             if r["ok"] and mode != 3:
                 assert np.abs(g["T"][i] - r["T"]).max() <= POSE_TOL
             else:
@@ -123,11 +132,11 @@ def test_image_align_ragged_point_counts(sd, oracle, rig):
             g = trk.get_align(0, B)
             for i in range(B):
                 o = rig["oras"][i]
-                pc = [o["oc"].level(l) for l in range(8)]
-                pr = [o["orf"].level(l) for l in range(8)]
+                pc = [o["oc"].level(l) for l in range(rig["NL"])]
+                pr = [o["orf"].level(l) for l in range(rig["NL"])]
                 Xw = cases[i]["Xw"][cases[i]["valid"] != 0]
                 r = oracle.align(pc, pr, o["tab"]["inv_sf"], o["tab"]["sf"], Xw, rig["scenes"][i]["T_ref"], Tinit[i], K, mode=mode)
-                assert g["ok"][i] == r["ok"] and np.array_equal(g["iters"][i][:8], r["iters"]), (mode, i, g["iters"][i][:8], r["iters"])
+                assert g["ok"][i] == r["ok"] and np.array_equal(g["iters"][i][:len(r["iters"])], r["iters"]), (mode, i, g["iters"][i][:len(r["iters"])], r["iters"])
                 if r["ok"] and mode != 3:
                     assert np.abs(g["T"][i] - r["T"]).max() <= POSE_TOL, (mode, i)
                 else:
@@ -354,10 +363,11 @@ def test_local_map_search_bit_exact(sd, oracle, rig):
     projections, predicted levels and the assignment vector equal the oracle's, for th = 1 / 3 / 5 (mono, RGB-D,
     after relocalisation: src/Tracking.cc:931-937), with claimed keypoints, stereo gates and a list overflow."""
     trk, B = rig["trk"], rig["B"]
-    log_sf = np.log(np.float32(CFG[1]))
+    log_sf = np.log(np.float32(rig["cfg"][1]))
     T = [s["T_cur"] for s in rig["scenes"]]
     trk.set_poses(0, [s["T_ref"] for s in rig["scenes"]], T)
-    cases = [synth.local_map_case(100 + i, rig["oras"][i]["ck"], rig["oras"][i]["cd"], T[i], n_extra=300 - 100 * (i % 2)) for i in range(B)]
+    cases = [synth.local_map_case(100 + i, rig["oras"][i]["ck"], rig["oras"][i]["cd"], T[i], n_extra=300 - 100 * (i % 2),
+                                  scale_factor=rig["cfg"][1], nlevels=rig["NL"]) for i in range(B)]
     # cap the local maps at the tracker's max_points
     cases = [{k: v[:1000] for k, v in c.items()} for c in cases]
     claimed = []
@@ -439,7 +449,8 @@ def test_pose_optimization_matches_oracle(sd, oracle, rig):
     # source 1: local-map matches
     Tc = [s["T_cur"] for s in rig["scenes"]]
     trk.set_poses(0, [s["T_ref"] for s in rig["scenes"]], Tc)
-    cases = [{k: v[:1000] for k, v in synth.local_map_case(200 + i, rig["oras"][i]["ck"], rig["oras"][i]["cd"], Tc[i]).items()} for i in range(B)]
+    cases = [{k: v[:1000] for k, v in synth.local_map_case(200 + i, rig["oras"][i]["ck"], rig["oras"][i]["cd"], Tc[i], scale_factor=rig["cfg"][1],
+                                                            nlevels=rig["NL"]).items()} for i in range(B)]
     trk.set_local(0, cases)
     trk.match_local(B, th=1.0, nnratio=0.8)
     lm = trk.get_local(0, B)["match"]
@@ -499,8 +510,8 @@ def test_track_with_motion_model_decisions(sd, oracle, rig):
             for i in range(B):
                 o = oras[i]
                 n = len(o["ck"])
-                pc = [o["oc"].level(l) for l in range(8)]
-                pr = [o["orf"].level(l) for l in range(8)]
+                pc = [o["oc"].level(l) for l in range(rig["NL"])]
+                pr = [o["orf"].level(l) for l in range(rig["NL"])]
                 T_dev_al = None if T_al is None else T_al[i]
                 r = oracle.track_with_motion_model(pc, pr, o["tab"], o["ck"], o["cd"], BOUNDS, K, scenes[i]["T_ref"], T0[i], lasts[i], th,
                                                    mono=True, align_mode=align_mode, T_aligned=T_dev_al)
@@ -528,12 +539,13 @@ def test_track_local_map_after_motion_model(sd, oracle, rig):
     match vectors, mnMatchesInliers decides.  Everything equals the oracle's composition of the stages."""
     trk, B = rig["trk"], rig["B"]
     scenes, oras = rig["scenes"], rig["oras"]
-    log_sf = np.log(np.float32(CFG[1]))
+    log_sf = np.log(np.float32(rig["cfg"][1]))
     lasts = [dict(o["last"]) for o in oras]
     for i, l in enumerate(lasts):       # a third of the last frame's points are not in the map yet (Observations() == 0)
         l["obs"] = (np.arange(len(l["obs"])) % 3 != i % 3).astype(np.int32)
     lasts[2]["valid"] = (np.arange(len(lasts[2]["valid"])) < 25).astype(np.uint8)       # frame 2 enters with few frame matches
-    cases = [{k: v[:1000] for k, v in synth.local_map_case(300 + i, oras[i]["ck"], oras[i]["cd"], scenes[i]["T_cur"]).items()} for i in range(B)]
+    cases = [{k: v[:1000] for k, v in synth.local_map_case(300 + i, oras[i]["ck"], oras[i]["cd"], scenes[i]["T_cur"], scale_factor=rig["cfg"][1],
+                                                            nlevels=rig["NL"]).items()} for i in range(B)]
     cases[3] = {k: v[:12] for k, v in cases[3].items()}                                  # frame 3 has an almost empty local map
     T0 = [synth.se3_exp((0.004, -0.003, 0.002), (0.05, 0.03, -0.04)) @ s["T_cur"] for s in scenes]
     trk.set_last(0, lasts)
@@ -604,8 +616,8 @@ def test_track_with_motion_model_rgbd(sd, oracle, rig):
                 o = oras[i]
                 n = len(o["ck"])
                 assert (ur[i, :n] >= 0).sum() > 300 and (ur[i, :n] < 0).sum() > 50       # stereo and mono edges
-                pc = [o["oc"].level(l) for l in range(8)]
-                pr = [o["orf"].level(l) for l in range(8)]
+                pc = [o["oc"].level(l) for l in range(rig["NL"])]
+                pr = [o["orf"].level(l) for l in range(rig["NL"])]
                 r = oracle.track_with_motion_model(pc, pr, o["tab"], o["ck"], o["cd"], BOUNDS, K, scenes[i]["T_ref"], T0[i], o["last"], th,
                                                    mono=False, align_mode=align_mode, u_right=ur[i, :n], mbf=bf, mb=mb,
                                                    T_aligned=None if T_al is None else T_al[i])
@@ -620,8 +632,8 @@ def test_track_with_motion_model_rgbd(sd, oracle, rig):
         trk.stereo_from_depth(np.zeros((B, 480, 640), np.float32))
 
 
-@pytest.fixture(scope="module")
-def kfmap(sd, oracle):
+@pytest.fixture(scope="module", params=["p8", "p5"])
+def kfmap(sd, oracle, request):
     """One current frame and 8 keyframes of a small map: six see the current frame's scene from nearby or distant
     poses, two show another place.  Slot order = the order the reference would try / list them."""
     tex_a, tex_b = synth.make_image(71, 1280, 960), synth.make_image(72, 1280, 960)
@@ -635,6 +647,7 @@ def kfmap(sd, oracle):
                  (tex_a, (0.012, -0.012, 0.008), (0.3, -0.25, 0.45)),       # closest
                  (tex_a, (-0.04, 0.02, 0.03), (-0.7, 0.5, 0.2))]            # medium
     NK = len(kf_motion)
+    CFG = CFGS[request.param]
     T_kf = [synth.se3_exp(u, w) for _, u, w in kf_motion]
     cur = sd.ORBextractor(*CFG, 640, 480, 1)
     ref = sd.ORBextractor(*CFG, 640, 480, NK)
@@ -654,7 +667,11 @@ def kfmap(sd, oracle):
     trk = sd.Tracker(cur, ref, max_points=1000, max_batch=NK, pnp_max_iterations=300)   # cur holds ONE frame
     trk.set_camera(*K, 0.0, BOUNDS)
     trk.set_last(0, [k["last"] for k in kfs])
-    return dict(NK=NK, T_cur=T_cur, T_kf=T_kf, trk=trk, cur=cur, ref=ref, oc=oc, ck=ock, cd=ocd, kfs=kfs, tab=oc.tables())
+    yield dict(NK=NK, T_cur=T_cur, T_kf=T_kf, trk=trk, cur=cur, ref=ref, oc=oc, ck=ock, cd=ocd, kfs=kfs, tab=oc.tables(), NL=CFG[2],
+               name=request.param)
+    trk.close()
+    cur.close()
+    ref.close()
 
 
 def test_relocalization_over_all_keyframes(sd, oracle, kfmap):
@@ -666,12 +683,12 @@ def test_relocalization_over_all_keyframes(sd, oracle, kfmap):
     th = 15.0
     winner, st = trk.relocalize(NK, cur_frame=0, th=th, mono=True)
     ga, (cm, nm), gp = trk.get_align(0, NK), trk.get_matches(0, NK), trk.get_pose_opt(0, NK)
-    pc = [m["oc"].level(l) for l in range(8)]
+    pc = [m["oc"].level(l) for l in range(m["NL"])]
     n = len(m["ck"])
     expect = -1
     for i in range(NK):
         k = m["kfs"][i]
-        pr = [k["orf"].level(l) for l in range(8)]
+        pr = [k["orf"].level(l) for l in range(m["NL"])]
         Xw = k["last"]["Xw"][k["last"]["valid"] != 0]
         ra = oracle.align(pc, pr, m["tab"]["inv_sf"], m["tab"]["sf"], Xw, m["T_kf"][i], m["T_kf"][i], K, mode=2)
         assert ga["ok"][i] == ra["ok"] == st[i, 0], i
@@ -690,7 +707,10 @@ def test_relocalization_over_all_keyframes(sd, oracle, kfmap):
         if expect < 0 and ra["ok"] and nmo >= 20 and rp["n_inliers"] >= 10:
             expect = i
     assert winner == expect
-    assert winner == 2                                      # the wrong-place and too-far keyframes fail one of the gates
+    # the wrong-place and too-far keyframes fail one of the gates.  8 x 1.2: the first close keyframe (slot 2) wins; 5 x 2.0: the
+    # fast alignment starts on a 40 x 30 image, where slots 2 ... 6 exceed its 0.01 error gate (src/ImageAlign.cc:159-163) in the
+    # oracle and on the device alike, and the loop stops at slot 7
+    assert winner == {"p8": 2, "p5": 7}[m["name"]]
     assert np.abs(gp["T"][winner][:3, 3] - m["T_cur"][:3, 3]).max() < 5e-3
     # no keyframe of the right place -> Relocalization returns false
     trk.set_last(0, [m["kfs"][0]["last"], m["kfs"][3]["last"]])
@@ -753,10 +773,10 @@ def test_detect_loop_candidates(sd, oracle, kfmap):
     for i in (3, 5):
         lasts[i]["valid"] = np.zeros_like(lasts[i]["valid"])
     trk.set_last(0, lasts)
-    pc = [m["oc"].level(l) for l in range(8)]
+    pc = [m["oc"].level(l) for l in range(m["NL"])]
     ok, err = [], []
     for i in range(NK):
-        pr = [m["kfs"][i]["orf"].level(l) for l in range(8)]
+        pr = [m["kfs"][i]["orf"].level(l) for l in range(m["NL"])]
         Xw = lasts[i]["Xw"][lasts[i]["valid"] != 0]
         r = oracle.align(pc, pr, m["tab"]["inv_sf"], m["tab"]["sf"], Xw, m["T_kf"][i], np.eye(4), K, mode=3)
         ok.append(r["ok"]); err.append(r["error"])
@@ -783,7 +803,11 @@ def test_detect_loop_candidates(sd, oracle, kfmap):
     assert sum(ok) >= 3 and not all(ok)
     g = trk.detect_loop(NK, cur_frame=0, excluded=None)
     assert list(g["candidates"]) == reference_loop([0] * NK)[0] and 6 not in g["candidates"]
-    assert 6 in trk.detect_loop(NK, cur_frame=0, excluded=[0, 0, 0, 1, 0, 1, 0, 0])["candidates"]
+    shifted = [0, 0, 0, 1, 0, 1, 0, 0]                      # excluding the point-less keyframes un-hides slots 4 and 6
+    g = trk.detect_loop(NK, cur_frame=0, excluded=shifted)
+    assert list(g["candidates"]) == reference_loop(shifted)[0]
+    if m["name"] == "p8":                                   # (on the 40 x 30 level-4 images of 5 x 2.0 slot 6 is aligned, but not within 1.5 x best)
+        assert 6 in g["candidates"]
     trk.set_last(0, [k["last"] for k in m["kfs"]])
 
 

@@ -20,7 +20,7 @@ K = (synth.FX, synth.FY, synth.CX, synth.CY)
 BOUNDS = (0.0, 640.0, 0.0, 480.0)
 
 for name, cfg in (("p8", (1000, 1.2, 8, 20)), ("p5", (1000, 2.0, 5, 20))):
-    for seed in (0, 1):
+    for seed in (0, 1, 2, 3):
         e = O.OrbOracle(*cfg)
         k, d = e.extract(synth.make_image(seed))
         np.savez_compressed(os.path.join(OUT, f"orb_{name}_seed{seed}.npz"), kps=k, desc=d,
@@ -77,6 +77,17 @@ for seed in (20,):
                         twc_info=np.array([twc["status"], twc["nmatches"], twc["nmatches_map"], twc["retried"]]), twc_match=twc["match"],
                         tl_info=np.array([tl["status"], tl["n_points"], tl["n_inliers"], tl["n_local"]]), tl_T=tl["T"],
                         tl_local_match=tl["local_match"], tl_outlier=tl["outlier"])
+
+# End-to-end goldens of the tracking step for BOTH pyramids -- p5 = the reference's own default
+# (src/Config.cc:48-51) -- and four scenes; what they hold: tests/e2e_cases.py
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import e2e_cases as EC                  # noqa: E402
+for name, cfg_ in EC.CFGS.items():
+    for seed in EC.SEEDS:
+        g = EC.oracle_case(O, cfg_, seed)
+        np.savez_compressed(os.path.join(OUT, f"e2e_{name}_seed{seed}.npz"), **g)
+        print(f"e2e {name} seed {seed}: align iters {g['al0_iters'].tolist()} ok {int(g['al0_ok'])}/{int(g['al2_ok'])}/{int(g['al3_ok'])}, "
+              f"{int(g['n_matches'])} matches, pnp {g['pnp_info'].tolist()}, poseopt inliers {int(g['po_n_inliers'])}, tw {g['tw_info'].tolist()}")
 print("golden written to", OUT, sorted(os.listdir(OUT)))
 
 # PnP RANSAC on planted-outlier match vectors (tests/pnp_cases.py): every iterate() call of every scenario
