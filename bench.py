@@ -442,6 +442,8 @@ def main():
                                                             "(ORBmatcher::SearchByPoints, 1000 x 1000 per frame pair)")
     ap.add_argument("--pyramid", default="8x1.2", help="LEVELSxSCALE: 8x1.2 = BASELINE configs[1]/[3] (the metric); 5x2.0 = the reference's own "
                                                        "default pyramid (src/Config.cc:48-51), reported beside it")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="sd_set_option before anything is created (A/B experiments; include/sdslam_hip.h lists the options)")
     ap.add_argument("--res", default="640x480", help="frame size WxH (BASELINE configs[4] uses 1280x720 frames; the metric is quoted at 640x480)")
     ap.add_argument("--pose-solver", choices=["pnp", "poseopt", "motion_model", "track"], default="pnp",
                     help="pnp: PnPsolver RANSAC (the BASELINE metric); poseopt: Optimizer::PoseOptimization, the pose solve the reference's "
@@ -496,6 +498,9 @@ def main():
 
     import sdslam_amd
     from sdslam_amd import dist_util
+    for ov in args.option:
+        name, val = ov.split("=")
+        sdslam_amd.set_option(name, int(val))
     wl = Workload(scenes, B, local_rank, args.pose_solver, args.orb_only, args.hamming, W, H, rank)
     cur, trk = wl.cur, wl.trk
     # per-frame records: written by the last tracking kernel (double-buffered), gathered from there
@@ -590,7 +595,7 @@ def main():
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload, "pose_solver": args.pose_solver, "pyramid": args.pyramid,
+            "config": {"workload": workload, "pose_solver": args.pose_solver, "pyramid": args.pyramid, "options": args.option,
                        "frames_per_gpu_per_step": B, "unique_scenes": nu, "inputs": "resident in HBM", "timed_region_s": dt,
                        "pose_records": ("REHEARSAL ONLY (SD_BENCH_REHEARSAL): all ranks on one GPU, gloo over host memory -- not a measurement" if rehearsal else
                                         "all-gathered over RCCL every step inside the timed region, straight from the device buffer the "

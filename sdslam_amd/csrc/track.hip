@@ -142,6 +142,10 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.al_iters, B * 16));
   A(dalloc(h, &tb.cur_match, B * K));
   A(dalloc(h, &tb.n_matches, B));
+  A(dalloc(h, &tb.mt_list, B * 8192));
+  A(dalloc(h, &tb.mt_pt, B * M));
+  A(dalloc(h, &tb.mt_key, B * 2048));
+  A(dalloc(h, &tb.mt_cstart, B * (64 * 48 + 4)));
   A(dalloc(h, &tb.uright, B * K));
   A(dalloc(h, &tb.depth, B * K));
   A(dalloc(h, &tb.rand_stream, B * (size_t)h->rand_per_frame));

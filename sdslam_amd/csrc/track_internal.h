@@ -33,6 +33,10 @@ struct TrackBuffers {
   // SearchByProjection outputs
   int32_t* cur_match;    // [B][kp_cap]  index into the last-frame arrays or -1
   int32_t* n_matches;    // [B]
+  uint32_t* mt_list;     // [B][8192] split matcher: candidate keys of the frame's points, in point order (track_match.hip)
+  uint32_t* mt_pt;       // [B][M]    ... offset << 16 | count of every point's keys
+  uint32_t* mt_key;      // [B][2048] ... the frame's sorted grid keys and cell starts (slow path of the assignment loop)
+  uint16_t* mt_cstart;   // [B][64*48+4]
   float* uright;         // [B][kp_cap]  CurrentFrame.mvuRight (-1: no stereo/depth information)
   float* depth;          // [B][kp_cap]  CurrentFrame.mvDepth
   // PnP

@@ -55,6 +55,14 @@ def rig(sd, oracle, request):
     ref.close()
 
 
+@pytest.fixture(params=[1, 0], ids=["split", "single"])
+def match_mode(sd, request):
+    """Both forms of SearchByProjection(Frame, Frame): candidate kernel + one-wave assignment kernel (the default; a frame whose
+    candidates do not fit its HBM list is handed to the single kernel) and the single 39-KB kernel alone."""
+    with sd.options({"track.match_split": request.param}):
+        yield request.param
+
+
 def _oracle_align(oracle, o, s, T0, mode=0):
     pc = [o["oc"].level(l) for l in range(len(o["tab"]["sf"]))]
     pr = [o["orf"].level(l) for l in range(len(o["tab"]["sf"]))]
@@ -145,7 +153,7 @@ def test_image_align_ragged_point_counts(sd, oracle, rig):
         trk.set_last(0, [o["last"] for o in rig["oras"]])
 
 
-def test_search_by_projection_bit_exact(sd, oracle, rig):
+def test_search_by_projection_bit_exact(sd, oracle, rig, match_mode):
     trk, B = rig["trk"], rig["B"]
     # th = 64: windows of hundreds of pixels overflow the LDS candidate list (per-point slow path of the kernel)
     for th, check_ori, use_truth in [(8.0, True, True), (16.0, True, False), (8.0, False, True), (64.0, True, True)]:
@@ -163,7 +171,7 @@ def test_search_by_projection_bit_exact(sd, oracle, rig):
             assert n > 50
 
 
-def test_match_overwrite_and_claim_semantics(sd, oracle, rig):
+def test_match_overwrite_and_claim_semantics(sd, oracle, rig, match_mode):
     """obs == 0 map points may be overwritten by later ones; obs > 0 ones block their keypoint."""
     trk, B = rig["trk"], rig["B"]
     cases = []
@@ -188,7 +196,7 @@ def test_match_overwrite_and_claim_semantics(sd, oracle, rig):
     trk.set_last(0, [o["last"] for o in rig["oras"]])     # restore
 
 
-def test_rgbd_stereo_gates_bit_exact(sd, oracle, rig):
+def test_rgbd_stereo_gates_bit_exact(sd, oracle, rig, match_mode):
     """RGB-D frames: ComputeStereoFromRGBD (mvuRight/mvDepth) and the bForward / bBackward / uRight gates of
     SearchByProjection (src/ORBmatcher.cc:965-966,999-1004,1020-1025).  bf = 4 (baseline 7.7 mm) so that the
     rig's centimetre motions land on both sides of the mb threshold."""
@@ -478,7 +486,7 @@ def test_pose_optimization_matches_oracle(sd, oracle, rig):
     trk.set_last(0, [o["last"] for o in rig["oras"]])
 
 
-def test_track_with_motion_model_decisions(sd, oracle, rig):
+def test_track_with_motion_model_decisions(sd, oracle, rig, match_mode):
     """Tracking::TrackWithMotionModel as one call (src/Tracking.cc:654-718): the per-frame decisions taken on the device
     (failed alignment keeps the prediction, wider-window retry from the prediction, the two failure exits, outlier discard,
     nmatchesMap) equal the oracle's stage-by-stage composition; final pose within 1e-5, final mvpMapPoints identical."""
