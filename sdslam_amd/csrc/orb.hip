@@ -4,9 +4,8 @@
 // every kernel takes the frame index as its outermost grid dimension, so one launch covers
 // all frames of a batch (and, for blur / selection / descriptors, all pyramid levels).
 //
-//   k_pyr_resize     ComputePyramid: resize        src/ORBextractor.cc:680-700 (interior pixels, table-driven bilinear)
-//   k_pyr_edges      ... copyMakeBorder columns    (left / right REFLECT_101 borders + unaligned interior remainder)
-//   k_pyr_rows       ... copyMakeBorder rows       (top / bottom border rows = copies of finished rows)
+//   k_pyr_split      ComputePyramid: resize + copyMakeBorder   src/ORBextractor.cc:680-700 (one launch per level: aligned 4-pixel
+//                    groups of every padded row, table-driven bilinear | left / right REFLECT_101 borders + unaligned remainder)
 //   k_pyr_level      same, single generic pass     (exact-2x INTER_AREA levels, byte-unaligned inputs, tiny levels)
 //   k_fast_cells     cv::FAST per grid cell        src/ORBextractor.cc:501-552 (FAST-9/16, score, cell-local 3x3 NMS)
 //   k_select_*       quota loop + retainBest       src/ORBextractor.cc:554-605 (wave-parallel libstdc++ introselect replay)
@@ -244,40 +243,41 @@ __global__ __launch_bounds__(256) void k_pyr_level(const LevelGeom L, const Leve
 // Split pyramid construction (the default path).  k_pyr_level above evaluates every padded pixel
 // through one code path, so the waves at both ends of a row run the slow reflected-border branch
 // as well as the interior one.  Here:
-//   k_pyr_resize  interior pixels only (padded columns 20 + 4g, interior rows), no reflection, no
+//   resize role   aligned 4-pixel groups (padded columns 20 + 4g) of every padded row, no column reflection, no
 //                 divergence: coefficient tables (the host's cv::resize tables), one aligned
 //                 12-byte window per source row, v_perm_b32 gathers the 2 x 4 source bytes;
-//   k_pyr_edges   the few interior pixels left of / right of the aligned groups and the left /
-//                 right REFLECT_101 borders of the interior rows, via pyr_px4 (generic path);
-//   k_pyr_rows    top / bottom border rows: copies of (complete) interior rows.
-// Level 0 is the frame copied into the padded layout by the same three kernels.
+//   edges role    the few interior pixels left of / right of the aligned groups and the left /
+//                 right REFLECT_101 borders of every padded row, via pyr_px4 (generic path).
+// Level 0 is the frame copied into the padded layout by the same kernel.
 // ------------------------------------------------------------------------------------------
 #ifndef PYR_RPT
 #define PYR_RPT 3
 #endif
 // rows per thread: rows Y, Y + ceil(h / 3), Y + 2 ceil(h / 3) share the x coefficients and give three independent load chains
 // (A/B on one box, full step: 3 rows 130.8 k, 2 rows 130.4 k frames/s; 4 rows were no better than 2 in r01i)
-__global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const LevelGeom S, size_t pyr_frame_bytes, int level,
-                                                    const int32_t* __restrict__ coef, const uint8_t* __restrict__ src0,
-                                                    int src_stride, size_t src_frame_stride, uint8_t* __restrict__ pyr,
-                                                    int G, unsigned magicG, int Hh) {
-  const int frame = blockIdx.y;
-  const unsigned e = blockIdx.x * 256 + threadIdx.x;
+// **r2**: the rows are PADDED rows (0 .. h + 37): a top / bottom border row is the resize of its REFLECT_101 interior row, computed
+// here like any other row instead of being copied by a third kernel after the first two (k_pyr_rows, gone); with that the two
+// remaining roles are independent and share ONE launch per level (k_pyr_split): 8 pyramid launches per step instead of 24.
+__device__ __forceinline__ void pyr_resize_body(const LevelGeom& L, const LevelGeom& S, size_t pyr_frame_bytes, int level,
+                                                const int32_t* __restrict__ coef, const uint8_t* __restrict__ src0, int src_stride,
+                                                size_t src_frame_stride, uint8_t* __restrict__ pyr, int G, unsigned magicG, int Hh,
+                                                int frame, unsigned e) {
   const unsigned Y0 = __umulhi(e, magicG);        // e / G
   if (Y0 >= (unsigned)Hh) return;
   const int g = (int)(e - Y0 * (unsigned)G);
   const int X0 = 1 + 4 * g;
   // wave-uniform base pointers + 32-bit per-lane offsets: loads and stores use the SGPR-base addressing form
   uint8_t* dstb = pyr + (size_t)frame * pyr_frame_bytes + L.off;
-  const uint32_t dst_x = (uint32_t)(SD_EDGE * L.pstride + X0 + SD_EDGE);
+  const uint32_t dst_x = (uint32_t)(X0 + SD_EDGE);
   uint32_t packed[PYR_RPT];
   bool live[PYR_RPT];
-  int Yr[PYR_RPT];
+  int Yr[PYR_RPT], PY[PYR_RPT];   // interior (source-side) row, padded (destination) row
 #pragma unroll
   for (int r = 0; r < PYR_RPT; r++) {
-    Yr[r] = (int)Y0 + r * Hh;
-    live[r] = Yr[r] < L.h;
-    if (!live[r]) Yr[r] = (int)Y0;   // duplicate work, not stored
+    PY[r] = (int)Y0 + r * Hh;
+    live[r] = PY[r] < L.prows;
+    if (!live[r]) PY[r] = (int)Y0;   // duplicate work, not stored
+    Yr[r] = reflect101(PY[r] - SD_EDGE, L.h);
   }
   if (level == 0) {
 #pragma unroll
@@ -354,36 +354,33 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelGeom L, const Lev
   }
 #pragma unroll
   for (int r = 0; r < PYR_RPT; r++)
-    if (live[r]) *(uint32_t*)(dstb + (dst_x + (uint32_t)__mul24(Yr[r], L.pstride))) = packed[r];
+    if (live[r]) *(uint32_t*)(dstb + (dst_x + (uint32_t)__mul24(PY[r], L.pstride))) = packed[r];
 }
 
-// interior rows: padded columns [0, 20) and [20 + 4 G, roundup4(w + 38)); one thread per 4 columns
-__global__ __launch_bounds__(256) void k_pyr_edges(const LevelGeom L, const LevelGeom S, size_t pyr_frame_bytes, int level,
-                                                   const uint8_t* __restrict__ src0, int src_stride, size_t src_frame_stride,
-                                                   uint8_t* __restrict__ pyr, int G, int T, unsigned magicT) {
-  const int frame = blockIdx.y;
-  const unsigned e = blockIdx.x * 256 + threadIdx.x;
-  const unsigned Y = __umulhi(e, magicT);        // e / T
-  if (Y >= (unsigned)L.h) return;
-  const int j = (int)(e - Y * (unsigned)T);
+// all padded rows: padded columns [0, 20) and [20 + 4 G, roundup4(w + 38)); one thread per 4 columns
+__device__ __forceinline__ void pyr_edges_body(const LevelGeom& L, const LevelGeom& S, size_t pyr_frame_bytes, int level,
+                                               const uint8_t* __restrict__ src0, int src_stride, size_t src_frame_stride,
+                                               uint8_t* __restrict__ pyr, int G, int T, unsigned magicT, int frame, unsigned e) {
+  const unsigned py = __umulhi(e, magicT);        // e / T
+  if (py >= (unsigned)L.prows) return;
+  const int j = (int)(e - py * (unsigned)T);
   const int px = j < 5 ? 4 * j : 20 + 4 * G + 4 * (j - 5);
-  const int py = (int)Y + SD_EDGE;
-  const uint32_t v = pyr_px4(L, S, pyr_frame_bytes, level, frame, px, py, src0, src_stride, src_frame_stride, pyr);
+  const uint32_t v = pyr_px4(L, S, pyr_frame_bytes, level, frame, px, (int)py, src0, src_stride, src_frame_stride, pyr);
   *(uint32_t*)(pyr + (size_t)frame * pyr_frame_bytes + L.off + (size_t)py * L.pstride + px) = v;
 }
 
-// top / bottom REFLECT_101 border rows: row py copies interior row reflect101(py - 19)
-__global__ __launch_bounds__(256) void k_pyr_rows(const LevelGeom L, size_t pyr_frame_bytes, uint8_t* __restrict__ pyr, int wpr /* dwords per row */,
-                                                  unsigned magicW) {
+// one launch per level: workgroups [0, n_resize) run the aligned-group resize, the rest the edge columns
+__global__ __launch_bounds__(256) void k_pyr_split(const LevelGeom L, const LevelGeom S, size_t pyr_frame_bytes, int level,
+                                                   const int32_t* __restrict__ coef, const uint8_t* __restrict__ src0, int src_stride,
+                                                   size_t src_frame_stride, uint8_t* __restrict__ pyr, int G, unsigned magicG, int Hh,
+                                                   int T, unsigned magicT, unsigned n_resize) {
   const int frame = blockIdx.y;
-  const unsigned e = blockIdx.x * 256 + threadIdx.x;
-  const unsigned r = __umulhi(e, magicW);        // e / wpr : 0 .. 2 * 19 - 1
-  if (r >= 2u * SD_EDGE) return;
-  const int wc = (int)(e - r * (unsigned)wpr);
-  const int py = r < SD_EDGE ? (int)r : L.h + (int)r;   // 0..18, then h+19 .. h+37
-  const int sy = reflect101(py - SD_EDGE, L.h) + SD_EDGE;
-  uint32_t* base = (uint32_t*)(pyr + (size_t)frame * pyr_frame_bytes + L.off);
-  base[(size_t)py * (L.pstride >> 2) + wc] = base[(size_t)sy * (L.pstride >> 2) + wc];
+  if (blockIdx.x < n_resize)
+    pyr_resize_body(L, S, pyr_frame_bytes, level, coef, src0, src_stride, src_frame_stride, pyr, G, magicG, Hh, frame,
+                    blockIdx.x * 256 + threadIdx.x);
+  else
+    pyr_edges_body(L, S, pyr_frame_bytes, level, src0, src_stride, src_frame_stride, pyr, G, T, magicT, frame,
+                   (blockIdx.x - n_resize) * 256 + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1403,14 +1400,10 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
     auto magic = [](unsigned d) { return (unsigned)(0xFFFFFFFFull / d) + 1u; };   // e / d == umulhi(e, magic) for e < 2^31 / d
     const int G = (L.w - 1) / 4;
     const int T = 5 + (((L.w + 2 * SD_EDGE + 3) & ~3) - 20 - 4 * G) / 4;
-    const int wpr = ((L.w + 2 * SD_EDGE + 3) & ~3) / 4;
-    const int Hh = (L.h + PYR_RPT - 1) / PYR_RPT;
-    hipLaunchKernelGGL(k_pyr_resize, dim3((unsigned)(((size_t)Hh * G + 255) / 256), n), dim3(256), 0, s, L, S, (size_t)P.pyr_frame_bytes,
-                       l, h->d_coef, d_imgs, stride, frame_stride, h->d_pyr, G, magic((unsigned)G), Hh);
-    hipLaunchKernelGGL(k_pyr_edges, dim3((unsigned)(((size_t)L.h * T + 255) / 256), n), dim3(256), 0, s, L, S, (size_t)P.pyr_frame_bytes,
-                       l, d_imgs, stride, frame_stride, h->d_pyr, G, T, magic((unsigned)T));
-    hipLaunchKernelGGL(k_pyr_rows, dim3((unsigned)((2 * SD_EDGE * wpr + 255) / 256), n), dim3(256), 0, s, L, (size_t)P.pyr_frame_bytes,
-                       h->d_pyr, wpr, magic((unsigned)wpr));
+    const int Hh = (L.prows + PYR_RPT - 1) / PYR_RPT;   // padded rows per row-slot of a thread
+    const unsigned n_resize = (unsigned)(((size_t)Hh * G + 255) / 256), n_edges = (unsigned)(((size_t)L.prows * T + 255) / 256);
+    hipLaunchKernelGGL(k_pyr_split, dim3(n_resize + n_edges, n), dim3(256), 0, s, L, S, (size_t)P.pyr_frame_bytes, l, h->d_coef, d_imgs,
+                       stride, frame_stride, h->d_pyr, G, magic((unsigned)G), Hh, T, magic((unsigned)T), n_resize);
     }
     // FAST of this level starts now, on its own stream
     // levels >= merge_from share ONE launch after the last level is complete (cells of consecutive levels are contiguous)

@@ -1,13 +1,13 @@
 #!/bin/bash
 # A/B of two bench.py configurations by ALTERNATING runs (A B A B ...), one JSON line per run into gpurun_out/<tag>_{a,b}<k>.json.
-#   tools/ab_bench.sh TAG N "ARGS_A" "ARGS_B"
+#   tools/ab_bench.sh TAG N "ARGS_A" "ARGS_B" ["ENV_B"]      ENV_B e.g. SD_LIB=tools/build/libsdslam_hip_base.so (another build of the library)
 # (decisions on the full step need alternating runs; a single pair is inside the run-to-run noise)
 set -e
-tag=$1; n=$2; a=$3; b=$4
+tag=$1; n=$2; a=$3; b=$4; envb=$5
 mkdir -p gpurun_out
 for k in $(seq 1 $n); do
   python bench.py --no-cpu-baseline --no-extras --steps 100 $a > gpurun_out/${tag}_a$k.json
-  python bench.py --no-cpu-baseline --no-extras --steps 100 $b > gpurun_out/${tag}_b$k.json
+  env $envb python bench.py --no-cpu-baseline --no-extras --steps 100 $b > gpurun_out/${tag}_b$k.json
 done
 python - <<PY
 import json,glob
