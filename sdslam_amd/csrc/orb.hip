@@ -462,6 +462,10 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t* __restrict__ c, 
   return max(a, -b) - 1;
 }
 
+typedef unsigned short fu16;
+__device__ __forceinline__ fu16 fmin16(fu16 a, fu16 b) { return a < b ? a : b; }
+__device__ __forceinline__ fu16 fmax16(fu16 a, fu16 b) { return a > b ? a : b; }
+
 // Corner test and cornerScore in one: with A = min over the 16 nine-arcs of max(p) and
 // B = max over the arcs of min(p), a 9-arc darker than v - th exists iff v - A > th, a brighter one iff
 // B - v > th, and cornerScore = max(v - A, B - v) - 1 (the same quantity as fast_corner_score: min / max
@@ -481,6 +485,9 @@ __device__ __forceinline__ int fast_ring_score(const uint8_t* __restrict__ c, in
     x3[k] = max(max(p[k], p[(k + 1) & 15]), p[(k + 2) & 15]);
     n3[k] = min(min(p[k], p[(k + 1) & 15]), p[(k + 2) & 15]);
   }
+  // (16-bit min / max for the final reductions would issue at 2.2 instead of 4.1 cycles, but the compiler then loses the
+  // v_max3 / v_min3 merges across the two stages, or fuses pairs into v_min3_u16 / v_max3_u16 at 8.1 cycles: 365 cycles per
+  // 64 pixels either way -- measured, profiles/r03_valu_microbench*.json)
   int A = 255, B = 0;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
@@ -577,6 +584,8 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
   uint8_t* tile = smem;
   uint8_t* sc = smem + (size_t)TP * (S + 2 + 6);
   uint16_t* queue = (uint16_t*)(sc + (size_t)SP * (S + 2 + 2)) + (size_t)wave * QCAP;
+  // the wave's queue as a scalar byte offset into the dynamic LDS (phase A stores through SGPR base + lane offset)
+  const uint32_t qbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)((size_t)TP * (S + 2 + 6) + (size_t)SP * (S + 2 + 2) + (size_t)wave * QCAP * 2));
   const unsigned magic = 0xFFFFFFFFu / (unsigned)zw + 1u;   // q / zw == umulhi(q, magic) for q < 2^16, zw < 2^12
   const unsigned magic_tpw = 0xFFFFFFFFu / (unsigned)TPW + 1u;   // tile dword index / TPW (indices < 2^16: the tile is < 64 KB)
   const unsigned long long lt = lanemask_lt();
@@ -623,19 +632,22 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
     for (int y = y_lo; y < y_hi; y++) {
       const uint8_t* rowc = tile + __mul24(y + 3, TP) + 3 + sh;
       for (int x0 = 0; x0 < zw; x0 += 64) {
-        const int x = x0 + lane;
-        bool pass = false;
-        if (x < zw) {
-          const uint8_t* c = rowc + x;
-          const int v = c[0], lo = v - th, hi = v + th;
-          const int p0 = c[3 * TP], p4 = c[3], p8 = c[-3 * TP], p12 = c[-3];
-          // comparisons stay lane masks (v_cmp -> SGPR pair) and are combined on the scalar unit
-          const bool k0 = p0 < lo, k4 = p4 < lo, k8 = p8 < lo, k12 = p12 < lo;
-          const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
-          pass = ((k0 | k8) & (k4 | k12)) | ((b0 | b8) & (b4 | b12));
-        }
+        // r3: straight-line code on 16-bit min / max.  The lanes beyond the zone read a clamped position and are masked out
+        // of the ballot on the scalar unit (a branch around the loads made the compiler rebuild the mask with v_cndmask +
+        // v_cmp); with D = max(min(p0, p8), min(p4, p12)) and Bt = min(max(p0, p8), max(p4, p12)) the compass condition
+        // ((k0 | k8) & (k4 | k12)) | ((b0 | b8) & (b4 | b12)), k = p < v - th, b = p > v + th, is max(v - D, Bt - v) > th:
+        // 9 full-rate 16-bit instructions and ONE compare instead of 6 half-rate min / max, two adds and two compares.
+        const int x = (int)fmin16((fu16)(x0 + lane), (fu16)(zw - 1));
+        const uint8_t* c = rowc + x;
+        const fu16 v = c[0], p0 = c[3 * TP], p4 = c[3], p8 = c[-3 * TP], p12 = c[-3];
+        const fu16 D = fmax16(fmin16(p0, p8), fmin16(p4, p12));
+        const fu16 Bt = fmin16(fmax16(p0, p8), fmax16(p4, p12));
+        const short da = (short)(v - D), db = (short)(Bt - v);
+        bool pass = (da > db ? da : db) > (short)th;
+        if (zw - x0 < 64) pass = pass && (x0 + lane < zw);   // wave-uniform branch: only a row's last chunk pays this compare
         const unsigned long long m = __ballot(pass);
-        if (pass) queue[qn + __popcll(m & lt)] = (uint16_t)(__mul24(y, zw) + x);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (pass) *(uint16_t*)(smem + (qbase + 2u * (uint32_t)(qn + rank))) = (uint16_t)(__mul24(y, zw) + x);
         qn += __popcll(m);
       }
     }
