@@ -152,7 +152,7 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.pnp_T, B * 16));
   A(dalloc(h, &tb.pnp_inliers, B * K));
   A(dalloc(h, &tb.pnp_info, B * 8));
-  A(dalloc(h, &tb.pnp_scratch, B * K * 12));
+  A(dalloc(h, &tb.pnp_scratch, B * K * 5));
   A(dalloc(h, &tb.pnp_pts, B * K * 6));
   A(dalloc(h, &tb.pnp_kpidx, B * K));
   A(dalloc(h, &tb.pnp_state, B * 4));

@@ -44,7 +44,7 @@ struct TrackBuffers {
   float* pnp_T;          // [B][16] row-major CV_32F 4x4
   uint8_t* pnp_inliers;  // [B][kp_cap]
   int32_t* pnp_info;     // [B][8]: ok, nInliers, noMore, iterations, N, minInliers, maxIts, refined
-  double* pnp_scratch;   // [B][kp_cap*12] EPnP per-correspondence work arrays (pws, us, alphas, pcs)
+  float* pnp_scratch;    // [B][kp_cap*5] EPnP refit: the best set's correspondences, compacted (pws f32 x 3 | us f32 x 2)
   float* pnp_pts;        // [B][kp_cap][6] gathered correspondences {u, v, X, Y, Z, maxErr}
   uint16_t* pnp_kpidx;   // [B][kp_cap] mvKeyPointIndices
   // PnPsolver members that persist between iterate() calls (sd_track_pnp constructs, sd_track_pnp_iterate continues)

@@ -692,45 +692,31 @@ __device__ __forceinline__ void epnp_alphas(const double* pi, const double cws[4
   a[0] = 1.0f - a[1] - a[2] - a[3];
 }
 
-// compute_L_6x10 / compute_rho from the four null-space rows of ut
+// L (6 x 10) and rho (6) of EPnP's beta system (src/PnPsolver.cc:716-764), table-driven.
+//   pair p = (kPairA[p], kPairB[p]) enumerates the six control-point pairs (0,1) (0,2) (0,3) (1,2) (1,3) (2,3);
+//   d_v[p] = (control point kPairA[p] - control point kPairB[p]) of null-space vector v (v = 0..3 <-> rows 11, 10, 9, 8 of ut);
+//   column c of L pairs null-space vectors (kColU[c], kColV[c]): L[p][c] = (u == v ? 1 : 2) * <d_u[p], d_v[p]>,
+//   the doubled entries being the cross terms of (sum_v beta_v d_v[p])^2;  rho[p] = |cw_a - cw_b|^2.
+// Operation order inside a dot product and the float literal of the doubling are what bit parity needs; everything else is indexing.
+__device__ const int8_t kPairA[6] = {0, 0, 0, 1, 1, 2}, kPairB[6] = {1, 2, 3, 2, 3, 3};
+__device__ const int8_t kColU[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3}, kColV[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3};
 template <typename Ptr>
 __device__ void epnp_L_rho(Ptr ut, const double cws[4][3], Ptr L, double rho[6], bool write_L) {
   if (write_L) {
-    const Ptr v4[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
-    double dv[4][6][3];
-    for (int i = 0; i < 4; i++) {
-      int a = 0, b = 1;
-      for (int j = 0; j < 6; j++) {
-        dv[i][j][0] = v4[i][3 * a] - v4[i][3 * b];
-        dv[i][j][1] = v4[i][3 * a + 1] - v4[i][3 * b + 1];
-        dv[i][j][2] = v4[i][3 * a + 2] - v4[i][3 * b + 2];
-        b++;
-        if (b > 3) {
-          a++;
-          b = a + 1;
-        }
+    for (int p = 0; p < 6; p++) {
+      double d[4][3];   // the pair's difference vector in each of the four null-space vectors
+      for (int v = 0; v < 4; v++) {
+        const Ptr nv = ut + 12 * (11 - v);
+        for (int k = 0; k < 3; k++) d[v][k] = nv[3 * kPairA[p] + k] - nv[3 * kPairB[p] + k];
+      }
+      Ptr row = L + 10 * p;
+      for (int c = 0; c < 10; c++) {
+        const double dp = dot3(d[kColU[c]], d[kColV[c]]);
+        row[c] = kColU[c] == kColV[c] ? dp : 2.0f * dp;
       }
     }
-    for (int i = 0; i < 6; i++) {
-      Ptr row = L + 10 * i;
-      row[0] = dot3(dv[0][i], dv[0][i]);
-      row[1] = 2.0f * dot3(dv[0][i], dv[1][i]);
-      row[2] = dot3(dv[1][i], dv[1][i]);
-      row[3] = 2.0f * dot3(dv[0][i], dv[2][i]);
-      row[4] = 2.0f * dot3(dv[1][i], dv[2][i]);
-      row[5] = dot3(dv[2][i], dv[2][i]);
-      row[6] = 2.0f * dot3(dv[0][i], dv[3][i]);
-      row[7] = 2.0f * dot3(dv[1][i], dv[3][i]);
-      row[8] = 2.0f * dot3(dv[2][i], dv[3][i]);
-      row[9] = dot3(dv[3][i], dv[3][i]);
-    }
   }
-  rho[0] = dist2_3(cws[0], cws[1]);
-  rho[1] = dist2_3(cws[0], cws[2]);
-  rho[2] = dist2_3(cws[0], cws[3]);
-  rho[3] = dist2_3(cws[1], cws[2]);
-  rho[4] = dist2_3(cws[1], cws[3]);
-  rho[5] = dist2_3(cws[2], cws[3]);
+  for (int p = 0; p < 6; p++) rho[p] = dist2_3(cws[kPairA[p]], cws[kPairB[p]]);
 }
 
 // find_betas_approx_{1,2,3} followed by gauss_newton (5 iterations).  The three variants depend
@@ -1017,19 +1003,29 @@ __device__ __forceinline__ void ordered_sums(int n, ldsd* terms, ldsd* out, F&& 
 // 16 pair an x- with a y-column of M and stay +0), inputs staged through LDS.  The 12 x 12 SVD
 // runs on lane 0, the three beta variants on lanes 0..2.  ut / L: lane 0's LDS views.
 // lds: terms[64 * 9], red[64], mtm[144].  Writes {R (row-major), t} to Rt_out[12] (LDS).
-template <typename Ptr>
-__device__ __noinline__ double epnp_refit_wave(int n, const double* pws, const double* us, double* alphas, double* pcs,
-                                               const EpnpCam cam, ldsd* Rt_out, Ptr ut, Ptr L, ldsd* terms, ldsd* red, ldsd* mtm) {
+// r3: pws / us are read where they lie -- TIn = float: the compacted copy of the gathered f32 correspondences (PnPsolver narrows
+// its 3-D points to Point3f and takes kp.pt, src/PnPsolver.cc:92-93; (double) of the same float is the same double) -- and the
+// barycentric coordinates (alphas) and camera-frame points (pcs) are RECOMPUTED from them wherever the reference reads its
+// alphas[] / pcs[] arrays (same expressions on the same inputs: same bits).  Round 2 kept all four as double arrays in HBM:
+// 96 bytes written and re-read several times per inlier, a third of the kernel's 19 x algorithmic traffic.
+template <typename Ptr, typename TIn>
+__device__ __noinline__ double epnp_refit_wave(int n, const TIn* pws, const TIn* us, const EpnpCam cam, ldsd* Rt_out, Ptr ut, Ptr L,
+                                               ldsd* terms, ldsd* red, ldsd* mtm) {
   const int lane = threadIdx.x & 63;
   double cws[4][3], ci[9];
+  auto PW = [&](int i, double* p) {
+    p[0] = (double)pws[3 * i];
+    p[1] = (double)pws[3 * i + 1];
+    p[2] = (double)pws[3 * i + 2];
+  };
   PROF_DECL;
   // choose_control_points
-  ordered_sums<3>(n, terms, red, [&](int i, double* tv) {
-    for (int k = 0; k < 3; k++) tv[k] = pws[3 * i + k];
-  });
+  ordered_sums<3>(n, terms, red, [&](int i, double* tv) { PW(i, tv); });
   for (int j = 0; j < 3; j++) cws[0][j] = red[j] / n;
   ordered_sums<6>(n, terms, red, [&](int i, double* tv) {
-    const double d0 = pws[3 * i] - cws[0][0], d1 = pws[3 * i + 1] - cws[0][1], d2 = pws[3 * i + 2] - cws[0][2];
+    double pw[3];
+    PW(i, pw);
+    const double d0 = pw[0] - cws[0][0], d1 = pw[1] - cws[0][1], d2 = pw[2] - cws[0][2];
     tv[0] = d0 * d0; tv[1] = d0 * d1; tv[2] = d0 * d2;
     tv[3] = d1 * d1; tv[4] = d1 * d2; tv[5] = d2 * d2;
   });
@@ -1048,8 +1044,12 @@ __device__ __noinline__ double epnp_refit_wave(int n, const double* pws, const d
     ci[i] = red[32 + i];
   }
   PROF(16);
-  // compute_barycentric_coordinates (lane-parallel; correspondence i always belongs to lane i % 64)
-  for (int i = lane; i < n; i += 64) epnp_alphas(pws + 3 * i, cws, ci, alphas + 4 * i);
+  // compute_barycentric_coordinates: on demand
+  auto AL = [&](int i, double* a) {
+    double pw[3];
+    PW(i, pw);
+    epnp_alphas(pw, cws, ci, a);
+  };
   for (int e = lane; e < 144; e += 64) mtm[e] = 0;
   PROF(17);
   // M^T M
@@ -1071,9 +1071,11 @@ __device__ __noinline__ double epnp_refit_wave(int n, const double* pws, const d
       __syncthreads();
       if (i < n) {
         ldsd* row = terms + lane * 7;
-        for (int k = 0; k < 4; k++) row[k] = alphas[4 * i + k];
-        row[4] = cam.uc - us[2 * i];
-        row[5] = cam.vc - us[2 * i + 1];
+        double a[4];
+        AL(i, a);
+        for (int k = 0; k < 4; k++) row[k] = a[k];
+        row[4] = cam.uc - (double)us[2 * i];
+        row[5] = cam.vc - (double)us[2 * i + 1];
       }
       __syncthreads();
       const int c = min(64, n - base);
@@ -1119,36 +1121,35 @@ __device__ __noinline__ double epnp_refit_wave(int n, const double* pws, const d
   for (int variant = 1; variant <= 3; variant++) {
     double ccs[4][3];
     epnp_ccs(ut, betas3[variant - 1], ccs);
-    // compute_pcs + solve_for_sign (decided by correspondence 0, which lane 0 holds)
-    double pc_first = 0;
-    for (int i = lane; i < n; i += 64) {
-      const double* a = alphas + 4 * i;
-      double* pc = pcs + 3 * i;
-      for (int j = 0; j < 3; j++) pc[j] = a[0] * ccs[0][j] + a[1] * ccs[1][j] + a[2] * ccs[2][j] + a[3] * ccs[3][j];
-      if (i == 0) pc_first = pc[2];
-    }
-    const bool flip = __shfl(pc_first, 0) < 0.0;
-    if (flip)
-      for (int i = lane; i < n; i += 64) {
-        pcs[3 * i] = -pcs[3 * i];
-        pcs[3 * i + 1] = -pcs[3 * i + 1];
-        pcs[3 * i + 2] = -pcs[3 * i + 2];
+    // compute_pcs + solve_for_sign (decided by correspondence 0): pc = sum_k alpha_k ccs_k, negated as a whole when pcs[0].z < 0
+    bool flip = false;
+    auto PC = [&](int i, double* pc) {
+      double a[4];
+      AL(i, a);
+      for (int j = 0; j < 3; j++) {
+        const double x = a[0] * ccs[0][j] + a[1] * ccs[1][j] + a[2] * ccs[2][j] + a[3] * ccs[3][j];
+        pc[j] = flip ? -x : x;
       }
+    };
+    {
+      double pc_first[3];
+      PC(0, pc_first);
+      flip = pc_first[2] < 0.0;
+    }
     // estimate_R_and_t
     double pc0[3], pw0[3], Rv[3][3], tv[3];
     ordered_sums<6>(n, terms, red, [&](int i, double* t6) {
-      for (int j = 0; j < 3; j++) {
-        t6[j] = pcs[3 * i + j];
-        t6[3 + j] = pws[3 * i + j];
-      }
+      PC(i, t6);
+      PW(i, t6 + 3);
     });
     for (int j = 0; j < 3; j++) {
       pc0[j] = red[j] / n;
       pw0[j] = red[3 + j] / n;
     }
     ordered_sums<9>(n, terms, red, [&](int i, double* t9) {
-      const double* pc = pcs + 3 * i;
-      const double* pw = pws + 3 * i;
+      double pc[3], pw[3];
+      PC(i, pc);
+      PW(i, pw);
       for (int j = 0; j < 3; j++) {
         t9[3 * j] = (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
         t9[3 * j + 1] = (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
@@ -1167,7 +1168,9 @@ __device__ __noinline__ double epnp_refit_wave(int n, const double* pws, const d
     for (int i = 0; i < 3; i++) tv[i] = red[25 + i];
     PROF(23);
     ordered_sums<1>(n, terms, red, [&](int i, double* t1) {
-      t1[0] = epnp_reproj_term(Rv, tv, pws + 3 * i, us[2 * i], us[2 * i + 1], cam);
+      double pw[3];
+      PW(i, pw);
+      t1[0] = epnp_reproj_term(Rv, tv, pw, (double)us[2 * i], (double)us[2 * i + 1], cam);
     });
     const double err = red[0] / n;
     __syncthreads();
@@ -1325,7 +1328,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
   const int total = max(maxIts, start + pp.n_iterations);
   const int32_t* rs = tb.rand_stream + (size_t)f * pp.rand_per_frame;
   int accepted = 0, acc_iters = 0, acc_cnt = 0;
-  double* scratch = tb.pnp_scratch + (size_t)f * cap * 12;
+  float* scratch = tb.pnp_scratch + (size_t)f * cap * 5;
   const int mset = pp.min_set;
   const int chunk = mset == 4 ? PNP_CHUNK : 1;
   __syncthreads();
@@ -1396,8 +1399,8 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
         }
       }
       __syncthreads();
-      double* pws = scratch;
-      double* us = scratch + 3 * (size_t)cap;
+      float* pws = scratch;
+      float* us = scratch + 3 * (size_t)cap;
       if (lane < mset) {
         const float* q = g_p + (size_t)s_draw[lane] * 6;
         pws[3 * lane] = q[2];
@@ -1407,8 +1410,8 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
         us[2 * lane + 1] = q[1];
       }
       __syncthreads();
-      epnp_refit_wave(mset, pws, us, scratch + 5 * (size_t)cap, scratch + 9 * (size_t)cap, cam, LDS_PTR(s_Rt[0]), r_ut, r_L, LDS_PTR(s_terms),
-                      LDS_PTR(s_red), LDS_PTR(s_mtm));
+      epnp_refit_wave(mset, (const float*)pws, (const float*)us, cam, LDS_PTR(s_Rt[0]), r_ut, r_L, LDS_PTR(s_terms), LDS_PTR(s_red),
+                      LDS_PTR(s_mtm));
     }
     __syncthreads();
     PROF(12);
@@ -1443,10 +1446,8 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
       if (new_best || refine_ok) {
         __syncthreads();
         // Refine(): EPnP on the best inlier set (wave-cooperative), then CheckInliers
-        double* pws = scratch;
-        double* us = scratch + 3 * (size_t)cap;
-        double* alphas = scratch + 5 * (size_t)cap;
-        double* pcs = scratch + 9 * (size_t)cap;
+        float* pws = scratch;                    // the best set's correspondences, compacted (20 bytes each)
+        float* us = scratch + 3 * (size_t)cap;
         {
           int n0 = 0;
           for (int w = 0; w < nwords; w++) {
@@ -1464,7 +1465,8 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
           }
         }
         __syncthreads();
-        epnp_refit_wave(best, pws, us, alphas, pcs, cam, LDS_PTR(s_RtRef), r_ut, r_L, LDS_PTR(s_terms), LDS_PTR(s_red), LDS_PTR(s_mtm));   // best == popcount(s_best)
+        epnp_refit_wave(best, (const float*)pws, (const float*)us, cam, LDS_PTR(s_RtRef), r_ut, r_L, LDS_PTR(s_terms), LDS_PTR(s_red),
+                        LDS_PTR(s_mtm));   // best == popcount(s_best)
         __syncthreads();
         int rcnt = 0;
         for (int w = 0; w < nwords; w++) {
@@ -1535,7 +1537,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
 }
 
 // diagnostics: EPnP alone on explicit correspondences (one lane)
-__global__ void k_epnp_debug(int n, const double* pws, const double* us, double* work, EpnpCam cam, double* out13) {
+__global__ void k_epnp_debug(int n, const double* pws, const double* us, EpnpCam cam, double* out13) {
   __shared__ double s_work[PNP_CHUNK * (156 + 60)];
   __shared__ double s_mtm[144], s_terms[64 * 9], s_red[64], s_Rt[12];
   __shared__ double s_Mrows[PNP_CHUNK * 4 * 24];
@@ -1561,7 +1563,7 @@ __global__ void k_epnp_debug(int n, const double* pws, const double* us, double*
     }
     __syncthreads();
   } else {
-    e = epnp_refit_wave(n, pws, us, work, work + 4 * (size_t)n, cam, LDS_PTR(s_Rt), ut, L, LDS_PTR(s_terms), LDS_PTR(s_red), LDS_PTR(s_mtm));
+    e = epnp_refit_wave(n, pws, us, cam, LDS_PTR(s_Rt), ut, L, LDS_PTR(s_terms), LDS_PTR(s_red), LDS_PTR(s_mtm));
   }
   if (lane == 0) {
     for (int i = 0; i < 12; i++) out13[i] = s_Rt[i];
@@ -1571,21 +1573,20 @@ __global__ void k_epnp_debug(int n, const double* pws, const double* us, double*
 
 int run_epnp_debug(int n, const double* Xw, const double* uv, double fx, double fy, double cx, double cy, double* R9, double* t3,
                    double* err) {
-  double *d_p = nullptr, *d_u = nullptr, *d_w = nullptr, *d_o = nullptr;
+  double *d_p = nullptr, *d_u = nullptr, *d_o = nullptr;
   SD_HIP_CHECK(hipMalloc(&d_p, sizeof(double) * 3 * n));
   SD_HIP_CHECK(hipMalloc(&d_u, sizeof(double) * 2 * n));
-  SD_HIP_CHECK(hipMalloc(&d_w, sizeof(double) * 7 * n));
   SD_HIP_CHECK(hipMalloc(&d_o, sizeof(double) * 13));
   SD_HIP_CHECK(hipMemcpy(d_p, Xw, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
   SD_HIP_CHECK(hipMemcpy(d_u, uv, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
   EpnpCam cam = {fx, fy, cx, cy};
-  hipLaunchKernelGGL(k_epnp_debug, dim3(1), dim3(64), 0, 0, n, d_p, d_u, d_w, cam, d_o);
+  hipLaunchKernelGGL(k_epnp_debug, dim3(1), dim3(64), 0, 0, n, d_p, d_u, cam, d_o);
   double out[13];
   SD_HIP_CHECK(hipMemcpy(out, d_o, sizeof(out), hipMemcpyDeviceToHost));
   for (int i = 0; i < 9; i++) R9[i] = out[i];
   for (int i = 0; i < 3; i++) t3[i] = out[9 + i];
   if (err) *err = out[12];
-  (void)hipFree(d_p); (void)hipFree(d_u); (void)hipFree(d_w); (void)hipFree(d_o);
+  (void)hipFree(d_p); (void)hipFree(d_u); (void)hipFree(d_o);
   return SD_OK;
 }
 
