@@ -323,18 +323,47 @@ class LoopClosing {
 class FrameTracker {
  public:
   FrameTracker(ORBextractor& cur, ORBextractor& last, int max_points = 2048, int pnp_max_iterations = 300)
-      : batch_(cur, last, max_points, 1, pnp_max_iterations), max_points_(max_points) {}
+      : batch_(cur, last, max_points, 1, pnp_max_iterations), max_points_(max_points), pnp_max_its_(pnp_max_iterations) {}
   TrackBatch& batch() { return batch_; }
+  // What the tracker's map-point arrays hold is remembered between calls: the three calls of one TrackWithMotionModel body
+  // (ComputePose, SearchByProjection, PoseOptimization on the same two frames) flatten and upload mLastFrame ONCE.  The key is
+  // (object address, mnId, N, the mvpMapPoints pointers and outlier flags); call this when a frame's map points were edited in
+  // place some other way (world positions moved by a bundle adjustment between two calls, say).
+  void InvalidateCache() { kind_ = NONE; }
 
   // bool ImageAlign::ComputePose(Frame &CurrentFrame, const Frame &LastFrame)          src/ImageAlign.h:36, src/Tracking.cc:668
   template <class FrameT>
   bool ComputePose(FrameT& CurrentFrame, const FrameT& LastFrame, double* error = nullptr) {
     Upload(CurrentFrame, LastFrame);
-    check(sd_track_align(batch_.handle(), 1, 0));
-    double T[16];
+    return Align(CurrentFrame, 0, error);
+  }
+  // bool ImageAlign::ComputePose(Frame &CurrentFrame, KeyFrame *LastKF, bool fast = false)
+  //                                                      src/ImageAlign.h:39, src/ImageAlign.cc:106-176, src/Tracking.cc:595,1077
+  // The points are LastKF->GetMapPoints() in ITS iteration order (a std::set<MapPoint*> in the reference: pointer order), the
+  // first 300 (100 when fast); neither isBad() nor outlier flags are looked at (src/ImageAlign.cc:129-136).  The `last`
+  // extractor must hold the keyframe's frame (its pyramid is what the reference reads from LastKF->mvImagePyramid).
+  template <class FrameT, class KeyFrameT>
+  bool ComputePose(FrameT& CurrentFrame, KeyFrameT* LastKF, bool fast = false, double* error = nullptr) {
+    SetCameraOf(CurrentFrame);
+    UploadSetPoints(LastKF);
+    const auto Tl = LastKF->GetPose();
+    const auto Tc = CurrentFrame.GetPose();
+    for (int i = 0; i < 16; i++) last_pose_[i] = Tl.data()[i];
+    check(sd_track_set_poses(batch_.handle(), 0, 1, Tl.data(), Tc.data()));
+    return Align(CurrentFrame, fast ? 2 : 1, error);
+  }
+  // bool ImageAlign::ComputePose(KeyFrame *CurrentKF, KeyFrame *LastKF)                src/ImageAlign.h:42, src/LoopClosing.cc:133
+  // level 4 only, identity start, rejected above 0.03; no pose is written.  The `cur` extractor holds CurrentKF's frame.
+  template <class KeyFrameT>
+  bool ComputePose(KeyFrameT* CurrentKF, KeyFrameT* LastKF, double* error = nullptr) {
+    SetCameraOf(*CurrentKF);
+    UploadSetPoints(LastKF);
+    const auto Tl = LastKF->GetPose();
+    const auto Tc = CurrentKF->GetPose();
+    check(sd_track_set_poses(batch_.handle(), 0, 1, Tl.data(), Tc.data()));
+    check(sd_track_align(batch_.handle(), 1, 3));
     int32_t ok = 0;
-    check(sd_track_get_align(batch_.handle(), 0, 1, T, error, &ok, nullptr, nullptr));
-    if (ok) SetPoseOf(CurrentFrame, T);
+    check(sd_track_get_align(batch_.handle(), 0, 1, nullptr, error, &ok, nullptr, nullptr));
     return ok != 0;
   }
   // int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
@@ -342,38 +371,102 @@ class FrameTracker {
   template <class FrameT>
   int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, float th, bool bMono, bool checkOrientation = true) {
     Upload(CurrentFrame, LastFrame);
-    if (!bMono) UploadURight(CurrentFrame, 0);   // RGB-D / stereo: the mvuRight gate of src/ORBmatcher.cc:1020-1025
-    check(sd_track_match(batch_.handle(), 1, th, bMono ? 1 : 0, checkOrientation ? 1 : 0));
-    std::vector<int32_t> idx(CurrentFrame.N > 0 ? cap(CurrentFrame) : 1);
-    int32_t n = 0;
-    check(sd_track_get_matches(batch_.handle(), 0, 1, idx.data(), (int)idx.size(), &n));
-    for (int i = 0; i < CurrentFrame.N; i++)
-      if (idx[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[idx[i]];   // the search only ever ASSIGNS
-    return n;
+    return Search(CurrentFrame, LastFrame.mvpMapPoints, th, bMono, checkOrientation);
+  }
+  // int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const float th, const bool bMono)
+  //                                                      src/ORBmatcher.h:52, src/ORBmatcher.cc:1077-1207, src/Tracking.cc:603,1083
+  // over pKF->GetMapPointMatches() (NULL and isBad() points skipped), octave / angle from pKF->mvKeys / mvKeysUn
+  template <class FrameT, class KeyFrameT>
+  int SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, float th, bool bMono, bool checkOrientation = true) {
+    SetCameraOf(CurrentFrame);
+    const auto vpMapPointMatches = pKF->GetMapPointMatches();
+    const int n = (int)vpMapPointMatches.size();
+    if (!Cached(KF_MATCHES, pKF, IdOf(*pKF, 0), n, vpMapPointMatches, nullptr)) {
+      LastFrameView v;
+      Blank(v, n);
+      for (int i = 0; i < n; i++) {
+        v.octave[i] = pKF->mvKeys[i].octave;
+        v.angle[i] = pKF->mvKeysUn[i].angle;
+        auto* p = vpMapPointMatches[i];
+        if (!p || p->isBad()) continue;
+        FillPoint(v, i, p);
+      }
+      batch_.SetLastFrame(0, v);
+    }
+    const auto Tl = pKF->GetPose();
+    const auto Tc = CurrentFrame.GetPose();
+    for (int i = 0; i < 16; i++) last_pose_[i] = Tl.data()[i];
+    check(sd_track_set_poses(batch_.handle(), 0, 1, Tl.data(), Tc.data()));
+    return Search(CurrentFrame, vpMapPointMatches, th, bMono, checkOrientation);
+  }
+  // int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
+  //                                                      src/ORBmatcher.h:47, src/ORBmatcher.cc:43-119, src/Tracking.cc:937
+  // on the isInFrustum results the caller's SearchLocalPoints left in the map points (mbTrackInView, mTrackProjX / Y / XR,
+  // mnTrackScaleLevel, mTrackViewCos); keypoints of F that already hold a point with Observations() > 0 stay closed.
+  template <class FrameT, class MapPointT>
+  int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, float th, float nnratio = 0.8f) {
+    SetCameraOf(F);
+    kind_ = NONE;
+    const int n = (int)vpMapPoints.size();
+    if (n > max_points_) throw Error(SD_ERR_CAPACITY, "more local map points than the tracker's max_points");
+    std::vector<uint8_t> in_view((size_t)max_points_, 0), desc((size_t)max_points_ * 32, 0), claimed((size_t)cap(F), 0);
+    std::vector<float> proj((size_t)max_points_ * 3, 0.f), vcos((size_t)max_points_, 0.f);
+    std::vector<int32_t> level((size_t)max_points_, 0), obs((size_t)max_points_, 0);
+    for (int i = 0; i < n; i++) {
+      auto* p = vpMapPoints[i];
+      if (!p->mbTrackInView || p->isBad()) continue;
+      in_view[i] = 1;
+      proj[(size_t)i * 3] = p->mTrackProjX; proj[(size_t)i * 3 + 1] = p->mTrackProjY; proj[(size_t)i * 3 + 2] = p->mTrackProjXR;
+      level[i] = p->mnTrackScaleLevel;
+      vcos[i] = p->mTrackViewCos;
+      const auto D = p->GetDescriptor();
+      for (int k = 0; k < 32; k++) desc[(size_t)i * 32 + k] = D.data[k];
+      obs[i] = p->Observations();
+    }
+    for (int i = 0; i < F.N; i++) claimed[i] = F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0;
+    UploadURight(F, 0);
+    check(sd_track_set_local_view(batch_.handle(), 0, 1, &n, in_view.data(), proj.data(), level.data(), vcos.data(), desc.data(), obs.data(),
+                                  claimed.data()));
+    check(sd_track_match_local_view(batch_.handle(), 1, th, nnratio));
+    std::vector<int32_t> idx(cap(F));
+    int32_t nm = 0;
+    check(sd_track_get_local(batch_.handle(), 0, 1, idx.data(), (int)idx.size(), &nm, nullptr, nullptr, nullptr, nullptr));
+    for (int i = 0; i < F.N; i++)
+      if (idx[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[idx[i]];
+    return nm;
   }
   // int Optimizer::PoseOptimization(Frame *pFrame)                                       src/Optimizer.h, src/Tracking.cc:693
-  // on whatever pFrame->mvpMapPoints holds (keypoint i <-> map point i; sd_track_set_matches)
+  // on whatever pFrame->mvpMapPoints holds.  Right behind a SearchByProjection on the same frame -- mvpMapPoints still exactly what
+  // that search assigned -- the matches and map points are already on the device and only the pose travels; otherwise keypoint
+  // i <-> map point i is flattened (sd_track_set_matches).
   template <class FrameT>
   int PoseOptimization(FrameT* pFrame) {
     FrameT& F = *pFrame;
     SetCameraOf(F);
-    LastFrameView v;
-    std::vector<int32_t> cm((size_t)F.N, -1);
-    v.valid.assign(F.N, 0); v.Xw.assign((size_t)F.N * 3, 0.0); v.desc.assign((size_t)F.N * 32, 0);
-    v.octave.assign(F.N, 0); v.angle.assign(F.N, 0.f); v.obs.assign(F.N, 0);
-    for (int i = 0; i < F.N; i++) {
-      auto* p = F.mvpMapPoints[i];
-      if (!p) continue;
-      v.valid[i] = 1;
-      cm[i] = i;
-      const auto X = p->GetWorldPos();
-      for (int k = 0; k < 3; k++) v.Xw[(size_t)i * 3 + k] = X(k);
-      v.obs[i] = p->Observations();
-    }
-    batch_.SetLastFrame(0, v);
+    bool resident = searched_frame_ == (const void*)pFrame && searched_id_ == IdOf(F, 0) && (int)assigned_.size() == F.N && kind_ != NONE &&
+                    kind_ != CUR_POINTS;
+    for (int i = 0; resident && i < F.N; i++) resident = (const void*)F.mvpMapPoints[i] == assigned_[i];
     const auto Tc = F.GetPose();
-    check(sd_track_set_poses(batch_.handle(), 0, 1, Tc.data(), Tc.data()));
-    check(sd_track_set_matches(batch_.handle(), 0, 1, cm.data(), F.N));
+    if (resident) {
+      check(sd_track_set_poses(batch_.handle(), 0, 1, last_pose_, Tc.data()));
+    } else {
+      LastFrameView v;
+      std::vector<int32_t> cm((size_t)F.N, -1);
+      Blank(v, F.N);
+      for (int i = 0; i < F.N; i++) {
+        auto* p = F.mvpMapPoints[i];
+        if (!p) continue;
+        v.valid[i] = 1;
+        cm[i] = i;
+        const auto X = p->GetWorldPos();
+        for (int k = 0; k < 3; k++) v.Xw[(size_t)i * 3 + k] = X(k);
+        v.obs[i] = p->Observations();
+      }
+      batch_.SetLastFrame(0, v);
+      kind_ = CUR_POINTS;
+      check(sd_track_set_poses(batch_.handle(), 0, 1, Tc.data(), Tc.data()));
+      check(sd_track_set_matches(batch_.handle(), 0, 1, cm.data(), F.N));
+    }
     UploadURight(F, 0);                        // stereo edges where mvuRight >= 0 (src/Optimizer.cc:262-300)
     check(sd_track_pose_opt(batch_.handle(), 1, 0));
     std::vector<uint8_t> outl(cap(F));
@@ -386,9 +479,110 @@ class FrameTracker {
     return info[5];
   }
 
+  // PnPsolver(const Frame &F, const vector<MapPoint*> &vpMapPointMatches) + SetRansacParameters + find / iterate
+  //                                                      src/PnPsolver.h:67-76, src/PnPsolver.cc:71-244
+  // (dead code in the reference; kept because BASELINE names it).  One solver per FrameTracker at a time.  rand_fn
+  // supplies what SD_SLAM::Random would draw from rand() (src/extra/utils.cc:23-26): minSet values per iteration, drawn up
+  // front for the iterations the call may run (the reference draws them one iteration at a time).
+  template <class FrameT, class MapPointT>
+  void PnPsolverConstruct(const FrameT& F, const std::vector<MapPointT*>& vpMapPointMatches) {
+    SetCameraOf(F);
+    const int n = (int)vpMapPointMatches.size();
+    LastFrameView v;
+    Blank(v, n);
+    std::vector<int32_t> cm((size_t)n, -1);
+    for (int i = 0; i < n; i++) {
+      auto* p = vpMapPointMatches[i];
+      if (!p || p->isBad()) continue;          // src/PnPsolver.cc:84-87
+      v.valid[i] = 1;
+      cm[i] = i;
+      const auto X = p->GetWorldPos();
+      for (int k = 0; k < 3; k++) v.Xw[(size_t)i * 3 + k] = X(k);
+    }
+    batch_.SetLastFrame(0, v);
+    kind_ = CUR_POINTS;
+    const auto Tc = F.GetPose();
+    check(sd_track_set_poses(batch_.handle(), 0, 1, Tc.data(), Tc.data()));
+    check(sd_track_set_matches(batch_.handle(), 0, 1, cm.data(), n));
+    pnp_n_ = n;
+    pnp_started_ = false;
+    SetRansacParameters();
+  }
+  void SetRansacParameters(double probability = 0.99, int minInliers = 8, int maxIterations = 300, int minSet = 4, float epsilon = 0.4f,
+                           float th2 = 5.991f) {
+    pnp_p_ = probability; pnp_min_inl_ = minInliers; pnp_max_iterations_ = maxIterations; pnp_min_set_ = minSet; pnp_eps_ = epsilon;
+    pnp_th2_ = th2;
+    pnp_started_ = false;
+  }
+  // cv::Mat iterate(int nIterations, bool &bNoMore, vector<bool> &vbInliers, int &nInliers): Tcw = 4 x 4 CV_32F row-major;
+  // returns false for the reference's empty Mat
+  template <class RandFn>
+  bool iterate(int nIterations, bool& bNoMore, std::vector<bool>& vbInliers, int& nInliers, float Tcw[16], RandFn rand_fn) {
+    if (pnp_n_ < 0) throw Error(SD_ERR_INVALID_ARG, "PnPsolverConstruct has not been called");
+    if (!pnp_started_) {
+      // the first call may run to max(mRansacMaxIts, nIterations) (the `||` of src/PnPsolver.cc:177); later calls add nIterations each
+      const int per_frame = 4 * pnp_max_its_;
+      std::vector<int32_t> r((size_t)per_frame);
+      for (auto& x : r) x = (int32_t)rand_fn();
+      check(sd_track_set_rand(batch_.handle(), 0, 1, r.data(), per_frame));
+      check(sd_track_pnp(batch_.handle(), 1, pnp_p_, pnp_min_inl_, pnp_max_iterations_, pnp_min_set_, pnp_eps_, pnp_th2_, nIterations));
+      pnp_started_ = true;
+    } else {
+      check(sd_track_pnp_iterate(batch_.handle(), 1, nIterations));
+    }
+    std::vector<uint8_t> inl((size_t)(pnp_n_ > max_points_ ? pnp_n_ : max_points_));
+    int32_t info[8];
+    check(sd_track_get_pnp(batch_.handle(), 0, 1, Tcw, inl.data(), (int)inl.size(), info));
+    bNoMore = info[2] != 0;
+    nInliers = info[1];
+    vbInliers.assign((size_t)pnp_n_, false);
+    for (int i = 0; i < pnp_n_; i++) vbInliers[i] = inl[i] != 0;
+    return info[0] != 0;
+  }
+  // cv::Mat find(vector<bool> &vbInliers, int &nInliers) { bool bFlag; return iterate(mRansacMaxIts, bFlag, vbInliers, nInliers); }
+  template <class RandFn>
+  bool find(std::vector<bool>& vbInliers, int& nInliers, float Tcw[16], RandFn rand_fn) {
+    bool bFlag;
+    return iterate(pnp_max_iterations_, bFlag, vbInliers, nInliers, Tcw, rand_fn);
+  }
+
  private:
+  enum Kind { NONE, FRAME_POINTS, KF_SET_POINTS, KF_MATCHES, CUR_POINTS };
   template <class FrameT>
   int cap(const FrameT& F) { return F.N > max_points_ ? F.N : max_points_; }
+  // frame / keyframe identity for the cache: mnId where the type has one (src/Frame.h:121, src/KeyFrame.h:112)
+  template <class T>
+  static auto IdOf(const T& F, int) -> decltype((unsigned long long)F.mnId) { return (unsigned long long)F.mnId; }
+  template <class T>
+  static unsigned long long IdOf(const T&, long) { return 0; }
+  static void Blank(LastFrameView& v, int n) {
+    v.valid.assign(n, 0); v.Xw.assign((size_t)n * 3, 0.0); v.desc.assign((size_t)n * 32, 0);
+    v.octave.assign(n, 0); v.angle.assign(n, 0.f); v.obs.assign(n, 0);
+  }
+  template <class MapPointT>
+  static void FillPoint(LastFrameView& v, int i, MapPointT* p) {
+    v.valid[i] = 1;
+    const auto X = p->GetWorldPos();
+    for (int k = 0; k < 3; k++) v.Xw[(size_t)i * 3 + k] = X(k);
+    const auto D = p->GetDescriptor();
+    for (int k = 0; k < 32; k++) v.desc[(size_t)i * 32 + k] = D.data[k];
+    v.obs[i] = p->Observations();
+  }
+  // is (kind, object, id, the pointer vector [+ outlier flags]) what the tracker's arrays already hold?  Records it otherwise.
+  template <class Vec>
+  bool Cached(Kind kind, const void* obj, unsigned long long id, int n, const Vec& pts, const std::vector<bool>* outl) {
+    bool same = kind_ == kind && key_obj_ == obj && key_id_ == id && (int)key_pts_.size() == n;
+    for (int i = 0; same && i < n; i++) same = key_pts_[i] == (const void*)pts[i] && (!outl || key_outl_[i] == (*outl)[i]);
+    if (same) return true;
+    kind_ = kind; key_obj_ = obj; key_id_ = id;
+    key_pts_.resize(n);
+    key_outl_.assign(n, false);
+    for (int i = 0; i < n; i++) {
+      key_pts_[i] = (const void*)pts[i];
+      if (outl) key_outl_[i] = (*outl)[i];
+    }
+    return false;
+  }
   // CurrentFrame.mvuRight (filled by Frame::ComputeStereoFromRGBD / ComputeStereoMatches in the reference's constructor)
   template <class FrameT>
   auto UploadURight(const FrameT& F, int) -> decltype((void)F.mvuRight) {
@@ -396,9 +590,11 @@ class FrameTracker {
   }
   template <class FrameT>
   void UploadURight(const FrameT&, long) {}   // frame types without mvuRight (monocular builds)
+  // Frame's camera members are static (src/Frame.h:109-112,175-178), KeyFrame's are per-object constants (src/KeyFrame.h:148,169-172):
+  // instance access reads both
   template <class FrameT>
   void SetCameraOf(const FrameT& F) {
-    batch_.SetCamera(FrameT::fx, FrameT::fy, FrameT::cx, FrameT::cy, F.mbf, FrameT::mnMinX, FrameT::mnMaxX, FrameT::mnMinY, FrameT::mnMaxY);
+    batch_.SetCamera(F.fx, F.fy, F.cx, F.cy, F.mbf, (float)F.mnMinX, (float)F.mnMaxX, (float)F.mnMinY, (float)F.mnMaxY);
   }
   template <class FrameT>
   static void SetPoseOf(FrameT& F, const double T[16]) {
@@ -406,33 +602,91 @@ class FrameTracker {
     for (int i = 0; i < 16; i++) M.data()[i] = T[i];
     F.SetPose(M);
   }
+  template <class FrameT>
+  bool Align(FrameT& CurrentFrame, int mode, double* error) {
+    check(sd_track_align(batch_.handle(), 1, mode));
+    double T[16];
+    int32_t ok = 0;
+    check(sd_track_get_align(batch_.handle(), 0, 1, T, error, &ok, nullptr, nullptr));
+    if (ok) SetPoseOf(CurrentFrame, T);
+    return ok != 0;
+  }
+  // the search on what the tracker's arrays hold; `source` = the pointer vector the indices refer to
+  template <class FrameT, class Vec>
+  int Search(FrameT& CurrentFrame, const Vec& source, float th, bool bMono, bool checkOrientation) {
+    if (!bMono) UploadURight(CurrentFrame, 0);   // RGB-D / stereo: the mvuRight gate of src/ORBmatcher.cc:1020-1025
+    check(sd_track_match(batch_.handle(), 1, th, bMono ? 1 : 0, checkOrientation ? 1 : 0));
+    std::vector<int32_t> idx(CurrentFrame.N > 0 ? cap(CurrentFrame) : 1);
+    int32_t n = 0;
+    check(sd_track_get_matches(batch_.handle(), 0, 1, idx.data(), (int)idx.size(), &n));
+    for (int i = 0; i < CurrentFrame.N; i++)
+      if (idx[i] >= 0) CurrentFrame.mvpMapPoints[i] = source[idx[i]];   // the search only ever ASSIGNS
+    // remembered for PoseOptimization's resident path: valid when the caller had cleared mvpMapPoints before the search, as
+    // every call site of the reference does (src/Tracking.cc:602,676,1080) -- PoseOptimization compares pointer by pointer
+    searched_frame_ = (const void*)&CurrentFrame;
+    searched_id_ = IdOf(CurrentFrame, 0);
+    assigned_.assign((size_t)CurrentFrame.N, nullptr);
+    for (int i = 0; i < CurrentFrame.N; i++)
+      if (idx[i] >= 0) assigned_[i] = (const void*)source[idx[i]];
+    return n;
+  }
+  // LastKF->GetMapPoints() in iteration order, the first 300 (what ImageAlign's KeyFrame overloads gather)
+  template <class KeyFrameT>
+  void UploadSetPoints(KeyFrameT* LastKF) {
+    const auto mappoints = LastKF->GetMapPoints();
+    std::vector<const void*> ptrs;
+    for (auto it = mappoints.begin(); it != mappoints.end() && (int)ptrs.size() < 300; ++it) ptrs.push_back((const void*)*it);
+    const int n = (int)ptrs.size();
+    if (n > max_points_) throw Error(SD_ERR_CAPACITY, "FrameTracker max_points below 300");
+    if (Cached(KF_SET_POINTS, LastKF, IdOf(*LastKF, 0), n, ptrs, nullptr)) return;
+    LastFrameView v;
+    Blank(v, n);
+    int i = 0;
+    for (auto it = mappoints.begin(); it != mappoints.end() && i < n; ++it, ++i) {
+      v.valid[i] = 1;
+      const auto X = (*it)->GetWorldPos();
+      for (int k = 0; k < 3; k++) v.Xw[(size_t)i * 3 + k] = X(k);
+    }
+    batch_.SetLastFrame(0, v);
+  }
   // what TrackWithMotionModel reads of mLastFrame (src/ImageAlign.cc:64-72, src/ORBmatcher.cc:968-1042) + both poses
   template <class FrameT>
   void Upload(const FrameT& CurrentFrame, const FrameT& LastFrame) {
     SetCameraOf(CurrentFrame);
-    LastFrameView v;
     const int n = LastFrame.N;
-    v.valid.assign(n, 0); v.Xw.assign((size_t)n * 3, 0.0); v.desc.assign((size_t)n * 32, 0);
-    v.octave.assign(n, 0); v.angle.assign(n, 0.f); v.obs.assign(n, 0);
-    for (int i = 0; i < n; i++) {
-      v.octave[i] = LastFrame.mvKeys[i].octave;
-      v.angle[i] = LastFrame.mvKeysUn[i].angle;
-      auto* p = LastFrame.mvpMapPoints[i];
-      if (!p || LastFrame.mvbOutlier[i]) continue;
-      v.valid[i] = 1;
-      const auto X = p->GetWorldPos();
-      for (int k = 0; k < 3; k++) v.Xw[(size_t)i * 3 + k] = X(k);
-      const auto D = p->GetDescriptor();
-      for (int k = 0; k < 32; k++) v.desc[(size_t)i * 32 + k] = D.data[k];
-      v.obs[i] = p->Observations();
+    if (!Cached(FRAME_POINTS, &LastFrame, IdOf(LastFrame, 0), n, LastFrame.mvpMapPoints, &LastFrame.mvbOutlier)) {
+      LastFrameView v;
+      Blank(v, n);
+      for (int i = 0; i < n; i++) {
+        v.octave[i] = LastFrame.mvKeys[i].octave;
+        v.angle[i] = LastFrame.mvKeysUn[i].angle;
+        auto* p = LastFrame.mvpMapPoints[i];
+        if (!p || LastFrame.mvbOutlier[i]) continue;
+        FillPoint(v, i, p);
+      }
+      batch_.SetLastFrame(0, v);
     }
-    batch_.SetLastFrame(0, v);
     const auto Tl = LastFrame.GetPose();
     const auto Tc = CurrentFrame.GetPose();
+    for (int i = 0; i < 16; i++) last_pose_[i] = Tl.data()[i];
     check(sd_track_set_poses(batch_.handle(), 0, 1, Tl.data(), Tc.data()));
   }
   TrackBatch batch_;
-  int max_points_;
+  int max_points_, pnp_max_its_;
+  Kind kind_ = NONE;
+  const void* key_obj_ = nullptr;
+  unsigned long long key_id_ = 0;
+  std::vector<const void*> key_pts_;
+  std::vector<bool> key_outl_;
+  const void* searched_frame_ = nullptr;
+  unsigned long long searched_id_ = 0;
+  std::vector<const void*> assigned_;
+  double last_pose_[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  int pnp_n_ = -1;
+  bool pnp_started_ = false;
+  double pnp_p_ = 0.99;
+  int pnp_min_inl_ = 8, pnp_max_iterations_ = 300, pnp_min_set_ = 4;
+  float pnp_eps_ = 0.4f, pnp_th2_ = 5.991f;
 };
 
 class PnPsolver {

@@ -129,6 +129,10 @@ int sd_orb_debug_level_keys(sd_orb* h, int frame, int level, uint32_t* keys_out,
  * elapsed ms per stage over the calls made since profiling was switched on (last 128 at most;
  * names from sd_orb_stage_name). */
 int sd_orb_set_stream(sd_orb* h, void* hip_stream);
+/* Ordering against a caller-owned hipStream_t (e.g. the stream that uploads the NEXT batch's frames while this batch is being
+ * processed): direction 0 = that stream waits for the extractions queued so far (their input frames may then be overwritten),
+ * 1 = the extractions queued from now on wait for everything queued on that stream so far (the upload of their frames). */
+int sd_orb_stream_fence(sd_orb* h, void* hip_stream, int direction);
 int sd_orb_sync(sd_orb* h);
 int sd_orb_set_profiling(sd_orb* h, int on);
 int sd_orb_num_stages(void);
@@ -204,6 +208,13 @@ int sd_track_set_local(sd_track* h, int frame0, int n_frames, const int32_t* n_l
                        const double* normal, const float* min_dist, const float* max_dist, const float* mf_max_dist,
                        const uint8_t* desc, const int32_t* obs, const uint8_t* kp_claimed);
 int sd_track_match_local(sd_track* h, int n_frames, float th, float nnratio, float viewing_cos_limit);
+/* The same search on the CALLER's isInFrustum results -- what ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+ * itself reads from the map points (src/ORBmatcher.cc:48-60): in_view = mbTrackInView && !isBad(), proj3 = {mTrackProjX,
+ * mTrackProjY, mTrackProjXR}, level = mnTrackScaleLevel, view_cos = mTrackViewCos; [n_frames][max_points] arrays.  Results
+ * through sd_track_get_local. */
+int sd_track_set_local_view(sd_track* h, int frame0, int n_frames, const int32_t* n_local, const uint8_t* in_view, const float* proj3,
+                            const int32_t* level, const float* view_cos, const uint8_t* desc, const int32_t* obs, const uint8_t* kp_claimed);
+int sd_track_match_local_view(sd_track* h, int n_frames, float th, float nnratio);
 int sd_track_get_local(sd_track* h, int frame0, int n_frames, int32_t* local_match, int cap, int32_t* n_matches,
                        uint8_t* in_view, float* proj3, int32_t* level, float* view_cos);
 

@@ -325,6 +325,11 @@ class ORBextractor:
     def set_stream(self, stream_ptr):
         _check(self.L.sd_orb_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
 
+    def stream_fence(self, stream_ptr, direction):
+        """sd_orb_stream_fence: 0 = the caller's stream waits for the extractions queued so far, 1 = later extractions wait for it."""
+        self.L.sd_orb_stream_fence.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _check(self.L.sd_orb_stream_fence(self.h, C.c_void_p(stream_ptr), direction))
+
     def sync(self):
         _check(self.L.sd_orb_sync(self.h))
 

@@ -1709,6 +1709,8 @@ void sd_orb_destroy(sd_orb* h) {
   if (h->ev_fast_done) (void)hipEventDestroy(h->ev_fast_done);
   if (h->ev_pyr_done) (void)hipEventDestroy(h->ev_pyr_done);
   if (h->ev_blur_done) (void)hipEventDestroy(h->ev_blur_done);
+  for (int i = 0; i < 2; i++)
+    if (h->ev_user_fence[i]) (void)hipEventDestroy(h->ev_user_fence[i]);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -1946,6 +1948,26 @@ int sd_orb_set_stream(sd_orb* h, void* hip_stream) {
   SD_HIP_CHECK(hipSetDevice(h->device));
   SD_HIP_CHECK(hipStreamSynchronize(h->stream));
   h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return SD_OK;
+}
+
+// Ordering against a caller's HIP stream (an upload stream that fills the frames of the next batch while this one is being
+// processed).  direction 0: `hip_stream` waits for everything queued on the extraction stream so far (the frames of the
+// extractions queued so far have been consumed when it proceeds); 1: the extraction stream -- and with it the FAST stream,
+// which is ordered behind it at the start of every extraction -- waits for everything queued on `hip_stream` so far.
+int sd_orb_stream_fence(sd_orb* h, void* hip_stream, int direction) {
+  SD_REQUIRE(h && (direction == 0 || direction == 1), SD_ERR_INVALID_ARG, "bad arguments");
+  SD_HIP_CHECK(hipSetDevice(h->device));
+  hipStream_t ext = (hipStream_t)hip_stream;
+  for (int i = 0; i < 2; i++)
+    if (!h->ev_user_fence[i]) SD_HIP_CHECK(hipEventCreateWithFlags(&h->ev_user_fence[i], hipEventDisableTiming));
+  if (direction == 0) {
+    SD_HIP_CHECK(hipEventRecord(h->ev_user_fence[0], h->stream));
+    SD_HIP_CHECK(hipStreamWaitEvent(ext, h->ev_user_fence[0], 0));
+  } else {
+    SD_HIP_CHECK(hipEventRecord(h->ev_user_fence[1], ext));
+    SD_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_user_fence[1], 0));
+  }
   return SD_OK;
 }
 

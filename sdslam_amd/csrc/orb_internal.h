@@ -38,6 +38,7 @@ struct sd_orb {
   int32_t* nout_set[2] = {nullptr, nullptr};
   hipEvent_t ev_set_free[2] = {nullptr, nullptr};
   bool set_busy[2] = {false, false};
+  hipEvent_t ev_user_fence[2] = {nullptr, nullptr};   // sd_orb_stream_fence
   hipEvent_t ev_extract_done = nullptr;   // end of the most recent extraction on `stream`
   bool extract_recorded = false;
   unsigned long long extract_serial = 0;  // extractions launched so far (a tracker checks that its inputs have not been replaced)

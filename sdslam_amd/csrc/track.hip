@@ -446,6 +446,47 @@ int sd_track_set_local(sd_track* h, int frame0, int n_frames, const int32_t* n_l
   return SD_OK;
 }
 
+// ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th) on the caller's OWN isInFrustum results
+// (reference src/ORBmatcher.cc:43-119 reads pMP->mbTrackInView, mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos, which
+// Frame::isInFrustum left in the MapPoint): sd_track_set_local_view uploads them, sd_track_match_local_view searches.
+// in_view[i] = mbTrackInView && !isBad().
+int sd_track_set_local_view(sd_track* h, int frame0, int n_frames, const int32_t* n_local, const uint8_t* in_view, const float* proj3,
+                            const int32_t* level, const float* view_cos, const uint8_t* desc, const int32_t* obs, const uint8_t* kp_claimed) {
+  TRACK_RANGE(h, frame0, n_frames);
+  SD_REQUIRE(n_local && in_view && proj3 && level && view_cos && desc && obs, SD_ERR_INVALID_ARG, "NULL argument");
+  const size_t M = h->max_points, o = (size_t)frame0, K = h->kp_cap;
+  for (int f = 0; f < n_frames; f++) {
+    SD_REQUIRE(n_local[f] >= 0 && n_local[f] <= h->max_points, SD_ERR_CAPACITY, "n_local exceeds max_points");
+    for (int i = 0; i < n_local[f]; i++)
+      SD_REQUIRE(!in_view[(size_t)f * M + i] || (level[(size_t)f * M + i] >= 0 && level[(size_t)f * M + i] < h->cur->nlevels), SD_ERR_INVALID_ARG,
+                 "mnTrackScaleLevel of an in-view point outside [0, nlevels)");
+  }
+  hipStream_t s = h->cur->stream;
+  const TrackBuffers& tb = h->tb;
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_n + o, n_local, (size_t)n_frames * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_inview + o * M, in_view, n_frames * M, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_proj + o * M * 3, proj3, n_frames * M * 12, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_level + o * M, level, n_frames * M * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_cos + o * M, view_cos, n_frames * M * 4, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_desc + o * M * 32, desc, n_frames * M * 32, hipMemcpyHostToDevice, s));
+  SD_HIP_CHECK(hipMemcpyAsync(tb.lm_obs + o * M, obs, n_frames * M * 4, hipMemcpyHostToDevice, s));
+  if (kp_claimed) SD_HIP_CHECK(hipMemcpyAsync(tb.lm_kclaim + o * K, kp_claimed, n_frames * K, hipMemcpyHostToDevice, s));
+  else SD_HIP_CHECK(hipMemsetAsync(tb.lm_kclaim + o * K, 0, n_frames * K, s));
+  SD_HIP_CHECK(hipStreamSynchronize(s));
+  return SD_OK;
+}
+
+int sd_track_match_local_view(sd_track* h, int n_frames, float th, float nnratio) {
+  int rc = check_ready(h, n_frames);
+  if (rc != SD_OK) return rc;
+  hipStream_t s = h->pnp_stream;
+  rc = wait_inputs(h, false);
+  if (rc != SD_OK) return rc;
+  rc = launch_match_local(h->cur, h->tb, h->cam, h->d_sf, h->d_scale_thr, h->cur->nlevels, n_frames, th, nnratio, 0.f, s, 0, 1);
+  if (rc == SD_OK) rc = mark_reads(h, false);
+  return rc;
+}
+
 // Frame::isInFrustum for every candidate + ORBmatcher::SearchByProjection(F, vpMapPoints, th) with mfNNratio = nnratio,
 // at the frames' current poses (sd_track_set_poses / the ImageAlign result)
 int sd_track_match_local(sd_track* h, int n_frames, float th, float nnratio, float viewing_cos_limit) {

@@ -114,7 +114,8 @@ int launch_pose_opt(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& c
 // claim_from_matches: "keypoint already holds a point with Observations() > 0" is read off the frame-to-frame matches
 // (tb.cur_match / tb.obs) instead of the caller's lm_kclaim flags
 int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, const float* d_scale_thr,
-                       int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s, int claim_from_matches = 0);
+                       int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s, int claim_from_matches = 0,
+                       int frustum_given = 0);
 int launch_features_in_area(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, int frame, float x, float y, float r,
                             int min_level, int max_level, int32_t* d_out, int out_cap, int32_t* d_n, int32_t* d_grid, hipStream_t s);
 int launch_search_points(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, int n_frames, float nnratio, int check_ori,

@@ -760,7 +760,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
                                                                 const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
                                                                 const float* __restrict__ sf, const float* __restrict__ scale_thr,
                                                                 int nlevels, float th, float nnratio, float cos_limit, int KP2,
-                                                                int claim_from_matches) {
+                                                                int claim_from_matches, int frustum_given) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int MP = tb.max_points;
   uint32_t* s_key = (uint32_t*)smem;
@@ -840,8 +840,10 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
   if (tid == 0) *s_nlist = 0;
   __syncthreads();
   grid_sort_and_starts(s_key, s_cstart, KP2, tid, NT);
-  // ---- isInFrustum, one thread per point
-  {
+  // ---- isInFrustum, one thread per point (frustum_given: the caller's own Frame::isInFrustum results -- mbTrackInView,
+  // mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos, uploaded by sd_track_set_local_view -- are used as they are, which is
+  // what ORBmatcher::SearchByProjection(F, vpMapPoints, th) itself reads, src/ORBmatcher.cc:48-60)
+  if (!frustum_given) {
     const double* Tc = tb.Tcur + (size_t)f * 16;   // column-major
     double R[3][3], t[3], Ow[3];
     for (int r = 0; r < 3; r++) {
@@ -1075,7 +1077,8 @@ int launch_features_in_area(const sd_orb* cur, const TrackBuffers& tb, const Tra
 }
 
 int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, const float* d_scale_thr,
-                       int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s, int claim_from_matches) {
+                       int nlevels, int n_frames, float th, float nnratio, float cos_limit, hipStream_t s, int claim_from_matches,
+                       int frustum_given) {
   int KP2 = 64;
   while (KP2 < tb.kp_cap) KP2 <<= 1;
   SD_REQUIRE(KP2 <= MT_MAXKP && tb.max_points <= 2048, SD_ERR_CAPACITY, "matcher supports at most 2048 keypoints / map points per frame");
@@ -1083,7 +1086,7 @@ int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam
   const size_t lds = (size_t)KP2 * 4 + MT_LIST_CAP * 4 + (size_t)MP * 4 + (size_t)((MP + 31) >> 5) * 4 + (size_t)(KP2 >> 5) * 4 + (size_t)KP2 * 2 +
                      (GRID_COLS * GRID_ROWS + 2) * 2 + (size_t)KP2 + 4 + 8;
   hipLaunchKernelGGL(k_match_local, dim3(n_frames), dim3(64 * MT_WAVES), lds, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_desc,
-                     cur->d_nout, tb, cam, d_sf, d_scale_thr, nlevels, th, nnratio, cos_limit, KP2, claim_from_matches);
+                     cur->d_nout, tb, cam, d_sf, d_scale_thr, nlevels, th, nnratio, cos_limit, KP2, claim_from_matches, frustum_given);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
 }

@@ -124,10 +124,12 @@ def test_tracker_behind_graph_replayed_extraction(sd):
     assert outs[0]["nm"].min() > 50
 
 
-def test_cpp_frame_overloads_run_the_motion_model_body(sd, oracle, tmp_path):
-    """The C++ drop-in path end to end on the GPU: tests/native/facade_frame.cc (reference-shaped Frame / MapPoint types
-    through FrameTracker::ComputePose / SearchByProjection / PoseOptimization, i.e. src/Tracking.cc:668-693) against the
-    oracle on the same two frames."""
+def test_cpp_frame_overloads_run_the_reference_call_sequences(sd, oracle, tmp_path):
+    """The C++ drop-in path end to end on the GPU: tests/native/facade_frame.cc drives FrameTracker's overloads with
+    reference-shaped Frame / KeyFrame / MapPoint types through the bodies of TrackWithMotionModel (src/Tracking.cc:668-693),
+    SearchLocalPoints' search (:937), PnPsolver(F, matches) + find(), TrackReferenceKeyFrame (:583-644), one turn of
+    Relocalization (:1069-1092) and one of DetectLoop (src/LoopClosing.cc:132-134); every printed result is compared with the
+    oracle's composition of the same calls on the same two frames."""
     import struct
     s = synth.make_scene(20)
     cfg = (1000, 1.2, 8, 20)
@@ -136,6 +138,19 @@ def test_cpp_frame_overloads_run_the_motion_model_body(sd, oracle, tmp_path):
     rk, rd = orf.extract(s["ref"])
     last = synth.tracking_case(20, rk, rd)
     T0 = synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04)) @ s["T_cur"]
+    tab = oc.tables()
+    pc, pr = [oc.level(l) for l in range(8)], [orf.level(l) for l in range(8)]
+    # ---- the oracle's TrackWithMotionModel body (needed first: the local map's isInFrustum results hang on its pose)
+    al = oracle.align(pc, pr, tab["inv_sf"], tab["sf"], last["Xw"][last["valid"] != 0], s["T_ref"], T0, K, 0)
+    Ta = al["T"] if al["ok"] else T0
+    nm, cm = oracle.search_by_projection(ck, cd, tab["sf"], BOUNDS, K, Ta, s["T_ref"], last, th=8.0)
+    Xw = np.zeros((len(ck), 3))
+    Xw[cm >= 0] = last["Xw"][cm[cm >= 0]]
+    po = oracle.pose_optimization(ck, cm >= 0, Xw, tab["inv_sigma2"], K, Ta)
+    kept = (cm >= 0) & (po["outlier"] == 0)                      # after "Discard outliers"
+    pts = {k: v[:1000] for k, v in synth.local_map_case(7, ck, cd, s["T_cur"]).items()}
+    lm = oracle.search_local_points(ck, cd, tab["sf"], np.log(np.float32(1.2)), BOUNDS, K, 0.0, po["T"], pts, th=1.0, nnratio=0.8,
+                                    kp_claimed=kept.astype(np.uint8))
     raw = tmp_path / "frames.bin"
     with open(raw, "wb") as f:
         f.write(s["cur"].tobytes())
@@ -146,6 +161,12 @@ def test_cpp_frame_overloads_run_the_motion_model_body(sd, oracle, tmp_path):
         f.write(struct.pack("<i", len(idx)))
         for i in idx:
             f.write(struct.pack("<i3d", int(i), *last["Xw"][i]))
+        M = len(pts["cand"])
+        f.write(struct.pack("<i", M))
+        for i in range(M):
+            f.write(struct.pack("<3d", *pts["Xw"][i]) + pts["desc"][i].tobytes() +
+                    struct.pack("<ii3fif", int(pts["obs"][i]), int(lm["in_view"][i]), *[float(v) for v in lm["proj"][i]], int(lm["level"][i]),
+                                float(lm["cos"][i])))
     exe = str(tmp_path / "facade_frame")
     libdir = os.path.dirname(sd.lib_path())
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-DRUN_ON_GPU", "-I", os.path.join(ROOT, "include"),
@@ -153,20 +174,67 @@ def test_cpp_frame_overloads_run_the_motion_model_body(sd, oracle, tmp_path):
                            f"-Wl,-rpath,{libdir}"])
     out = subprocess.run([exe, str(raw)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-2000:])
-    res = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
-    mat = [l for l in out.stdout.splitlines() if l.startswith("MATCH")][0].split()[1:]
-    N, nmatches, ngood, nout = (int(v) for v in res[1:5])
-    T = np.array([float(v) for v in res[5:21]]).reshape(4, 4).T
-    got_match = np.array([int(v) for v in mat], np.int32)
-    # the oracle's composition of the same three calls
-    tab = oc.tables()
-    al = oracle.align([oc.level(l) for l in range(8)], [orf.level(l) for l in range(8)], tab["inv_sf"], tab["sf"],
-                      last["Xw"][last["valid"] != 0], s["T_ref"], T0, K, 0)
-    Ta = al["T"] if al["ok"] else T0
-    nm, cm = oracle.search_by_projection(ck, cd, tab["sf"], BOUNDS, K, Ta, s["T_ref"], last, th=8.0)
-    Xw = np.zeros((len(ck), 3))
-    Xw[cm >= 0] = last["Xw"][cm[cm >= 0]]
-    po = oracle.pose_optimization(ck, cm >= 0, Xw, tab["inv_sigma2"], K, Ta)
+    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l and l.split()[0].isupper()}
+
+    def pose(vals):
+        return np.array([float(v) for v in vals]).reshape(4, 4).T
+
+    # ---- TrackWithMotionModel
+    res = lines["RESULT"]
+    N, nmatches, ngood, nout = (int(v) for v in res[:4])
+    T = pose(res[4:20])
+    got_match = np.array([int(v) for v in lines["MATCH"]], np.int32)
     assert N == len(ck) and nmatches == nm and np.array_equal(got_match, cm)
     assert ngood == po["n_inliers"] and nout == int(po["outlier"][cm >= 0].sum())
     assert np.abs(T - po["T"]).max() <= 1e-5
+    # ---- SearchByProjection(F, vpMapPoints, th) on the caller's isInFrustum results
+    assert int(lines["RESULTLOCAL"][0]) == lm["n"] and lm["n"] > 100
+    assert np.array_equal(np.array([int(v) for v in lines["MATCHLOCAL"]], np.int32), lm["match"])
+    # ---- PnPsolver(F, frame matches) + find(): the unseeded rand() stream is glibc's seed-1 stream
+    assert np.array_equal(np.array([int(v) for v in lines["PNPMATCH"]]) != 0, kept)
+    Xk = np.zeros((len(ck), 3))
+    Xk[kept] = last["Xw"][cm[kept]]
+    p = oracle.PnPOracle(kept.astype(np.uint8), np.stack([ck["x"], ck["y"]], 1), ck["octave"], tab["sigma2"], Xk, K)
+    p.set_ransac(0.99, 10, 200, 4, 0.28, 5.991)
+    r = p.iterate(200, synth.glibc_rand_stream(1200))
+    rp = lines["RESULTPNP"]
+    assert int(rp[0]) == int(r["ok"]) == 1 and int(rp[1]) == r["n_inliers"]
+    assert np.array_equal(np.array([int(v) for v in lines["INLPNP"]]) != 0, r["inliers"] != 0)
+    assert np.abs(np.array([float(v) for v in rp[2:18]]).reshape(4, 4) - r["T"]).max() <= 1e-5
+    # ---- TrackReferenceKeyFrame: the keyframe's points in ITS std::set order (pointer order of this run, printed)
+    order = np.array([int(v) for v in lines["SETORDER"]])
+    assert sorted(order) == sorted(np.flatnonzero(last["valid"]))
+    rk_ = lines["RESULTKF"]
+    nm_kf, ngood_kf, nmap_kf, retried = (int(v) for v in rk_[:4])
+    T_al, T_fin = pose(rk_[4:20]), pose(rk_[20:36])
+    alk = oracle.align(pc, pr, tab["inv_sf"], tab["sf"], last["Xw"][order[:300]], s["T_ref"], s["T_ref"], K, 1)
+    assert alk["ok"] and np.abs(T_al - alk["T"]).max() <= 1e-5
+    nmk, cmk = oracle.search_by_projection(ck, cd, tab["sf"], BOUNDS, K, T_al, s["T_ref"], last, th=8.0)   # from the device's aligned pose
+    assert retried == 0 and nmk >= 20 and np.array_equal(np.array([int(v) for v in lines["MATCHKF"]], np.int32), cmk)
+    Xk2 = np.zeros((len(ck), 3))
+    Xk2[cmk >= 0] = last["Xw"][cmk[cmk >= 0]]
+    pok = oracle.pose_optimization(ck, cmk >= 0, Xk2, tab["inv_sigma2"], K, T_al)
+    assert ngood_kf == pok["n_inliers"] and nm_kf == nmk - int(pok["outlier"][cmk >= 0].sum())
+    assert nmap_kf == int(((cmk >= 0) & (pok["outlier"] == 0)).sum())            # every point has Observations() > 0 here
+    assert np.abs(T_fin - pok["T"]).max() <= 1e-5 and np.abs(T_fin[:3, 3] - s["T_cur"][:3, 3]).max() < 5e-3
+    # ---- one turn of Relocalization: ComputePose(F, KF, fast) from the keyframe's pose
+    rr = lines["RESULTRELOC"]
+    ok_r, nm_r, ngood_r = (int(v) for v in rr[:3])
+    T_al_r, T_fin_r = pose(rr[4:20]), pose(rr[20:36])
+    alr = oracle.align(pc, pr, tab["inv_sf"], tab["sf"], last["Xw"][order[:300]], s["T_ref"], s["T_ref"], K, 2)
+    assert ok_r == int(alr["ok"]) and abs(float(rr[3]) - alr["error"]) <= 1e-7 * max(1.0, abs(alr["error"]))
+    if alr["ok"]:
+        assert np.abs(T_al_r - alr["T"]).max() <= 1e-5
+        nmr, cmr = oracle.search_by_projection(ck, cd, tab["sf"], BOUNDS, K, T_al_r, s["T_ref"], last, th=8.0)
+        assert nm_r == nmr
+        if nmr >= 20:
+            Xr = np.zeros((len(ck), 3))
+            Xr[cmr >= 0] = last["Xw"][cmr[cmr >= 0]]
+            por = oracle.pose_optimization(ck, cmr >= 0, Xr, tab["inv_sigma2"], K, T_al_r)
+            assert ngood_r == por["n_inliers"] and np.abs(T_fin_r - por["T"]).max() <= 1e-5
+    else:
+        assert nm_r == -1 and np.abs(T_al_r - s["T_ref"]).max() == 0
+    # ---- one turn of DetectLoop: ComputePose(KF, KF)
+    rl = lines["RESULTLOOP"]
+    all_ = oracle.align(pc, pr, tab["inv_sf"], tab["sf"], last["Xw"][order[:300]], s["T_ref"], np.eye(4), K, 3)
+    assert int(rl[0]) == int(all_["ok"]) and abs(float(rl[1]) - all_["error"]) <= 1e-7 * max(1.0, abs(all_["error"]))

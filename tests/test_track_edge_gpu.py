@@ -238,3 +238,85 @@ def test_image_align_on_nearly_textureless_frames(sd, oracle, kind):
     trk.close()
     cur.close()
     ref.close()
+
+
+def test_two_host_threads_on_two_handle_sets(sd, oracle):
+    """SURVEY section 8(b) "Threading": Tracking runs on the caller's thread while LoopClosing::DetectLoop runs
+    ImageAlign(KF, KF) on its own (reference src/LoopClosing.cc:133); include/sdslam_hip.h promises that different handles
+    are independent.  One process, two host threads (ctypes releases the GIL for the duration of a call), each with its own
+    extractor pair + tracker: thread A loops extraction + TrackWithMotionModel on four frame pairs, thread B loops the
+    DetectLoop candidate search of one keyframe against 64 keyframes.  Every result of every iteration equals what the same
+    handles gave single-threaded (and that equals the oracle: a spot check on thread A's first frame)."""
+    import threading
+    from sdslam_amd.capi import DeviceBuffer
+    cfg = (1000, 1.2, 8, 20)
+    # ---- thread A's world
+    scenes = [synth.make_scene(20 + i) for i in range(4)]
+    curA, refA = sd.ORBextractor(*cfg, 640, 480, 4), sd.ORBextractor(*cfg, 640, 480, 4)
+    rk, rd, rn = refA.extract_batch(np.stack([s["ref"] for s in scenes]))
+    trkA = sd.Tracker(curA, refA, 1000, 4)
+    trkA.set_camera(*K, 0.0, BOUNDS)
+    lasts = [synth.tracking_case(i, rk[i, :rn[i]], rd[i, :rn[i]]) for i in range(4)]
+    trkA.set_last(0, lasts)
+    T0 = [synth.se3_exp((0.003, -0.002, 0.001), (0.05, 0.02, -0.04)) @ s["T_cur"] for s in scenes]
+    trkA.set_poses(0, [s["T_ref"] for s in scenes], T0)
+    fr = np.stack([s["cur"] for s in scenes])
+    dA = DeviceBuffer(fr.nbytes)
+    dA.upload(fr)
+
+    def step_a():
+        curA.extract_batch_device(dA.ptr, 4, 640, 480)
+        trkA.track_with_motion_model(4, th=8.0, mono=True, align_mode=0)
+        tw, po = trkA.get_tracked(0, 4), trkA.get_pose_opt(0, 4)
+        cm, _ = trkA.get_matches(0, 4)
+        return np.stack([tw["status"], tw["nmatches"], tw["nmatches_map"]]), po["T"].copy(), cm.copy()
+
+    # ---- thread B's world: one current keyframe against 64 keyframes (8 distinct views, tiled)
+    tex = synth.make_image(71, 1280, 960)
+    T_kf = [synth.se3_exp((0.01 * (i % 3 - 1), 0.008 * (i % 4 - 2), 0.005 * i), (0.2 * (i % 5 - 2), -0.1 * (i % 3), 0.15 * i)) for i in range(8)]
+    im_kf = np.stack([synth.render_plane_view(tex, T) for T in T_kf])
+    T_c = synth.se3_exp((0.015, -0.01, 0.01), (0.3, -0.2, 0.4))
+    curB, refB = sd.ORBextractor(*cfg, 640, 480, 1), sd.ORBextractor(*cfg, 640, 480, 64)
+    curB.extract_batch(synth.render_plane_view(tex, T_c)[None])
+    kk, kd, kn = refB.extract_batch(im_kf[np.arange(64) % 8])
+    trkB = sd.Tracker(curB, refB, 1000, 64)
+    trkB.set_camera(*K, 0.0, BOUNDS)
+    trkB.set_last(0, [synth.keyframe_case(kk[i, :kn[i]], kd[i, :kn[i]], T_kf[i % 8], max_points=400) for i in range(64)])
+    trkB.set_poses(0, [T_kf[i % 8] for i in range(64)], [np.eye(4)] * 64)
+    excluded = [1 if i % 11 == 0 else 0 for i in range(64)]
+
+    def step_b():
+        g = trkB.detect_loop(64, cur_frame=0, excluded=excluded)
+        return np.array(g["candidates"]), np.array(g["errors"]), np.float64(g["best_error"])
+
+    a0, b0 = step_a(), step_b()
+    assert (a0[0][0] == 2).all() and len(b0[0]) >= 1
+    # spot check against the oracle (thread A, frame 0)
+    oc, orf = oracle.OrbOracle(*cfg), oracle.OrbOracle(*cfg)
+    ock, ocd = oc.extract(scenes[0]["cur"])
+    orf.extract(scenes[0]["ref"])
+    r = oracle.track_with_motion_model(_levels(oc, 8), _levels(orf, 8), oc.tables(), ock, ocd, BOUNDS, K, scenes[0]["T_ref"], T0[0], lasts[0], 8.0,
+                                       mono=True)
+    assert a0[0][1][0] == r["nmatches"] and np.array_equal(a0[2][0, :len(ock)], r["match"]) and np.abs(a0[1][0] - r["T"]).max() <= POSE_TOL
+    errors = []
+
+    def run(step, want, n):
+        try:
+            for k in range(n):
+                got = step()
+                for x, y in zip(got, want):
+                    if not np.array_equal(x, y):
+                        raise AssertionError(f"iteration {k}: result differs from the single-threaded one")
+        except Exception as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+
+    ta = threading.Thread(target=run, args=(step_a, a0, 25))
+    tb = threading.Thread(target=run, args=(step_b, b0, 25))
+    ta.start()
+    tb.start()
+    ta.join(300)
+    tb.join(300)
+    assert not ta.is_alive() and not tb.is_alive()
+    assert not errors, errors
+    for h in (trkA, trkB, curA, refA, curB, refB):
+        h.close()
