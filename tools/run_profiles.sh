@@ -15,4 +15,6 @@ timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IN
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $ROOT/bench.py $ARGS > $OUT/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $ROOT/bench.py $ARGS > $OUT/write.log 2>&1
 python $ROOT/tools/pmc_summary.py $OUT/sq $OUT/fetch $OUT/write $OUT/trace > $OUT/pmc_summary.json
+python $ROOT/tools/fetch_calib_fast.py $OUT/fetch 1024 > $OUT/fetch_calibration_fast.json
+AMD_SERIALIZE_KERNEL=3 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serialized -o t -- python $ROOT/bench.py --no-cpu-baseline --no-extras --steps 30 > $OUT/trace_serialized.log 2>&1
 ls $OUT
