@@ -47,6 +47,8 @@ const char* sd_version(void);
  *   track.poseopt_waves        0     k_pose_opt waves per frame: 0 = by batch size (4 up to 256 frames, else 1), 1, 4
  *   track.match_split          1     SearchByProjection(Frame, Frame / KeyFrame) as candidate + one-wave assignment kernels
  *                                    (6 KB of LDS per frame through the serial part); 0: the single 39-KB kernel
+ *   extract.fast0_early        1     device-input extractions: FAST of level 0 starts behind the PREVIOUS call's selection (beside its
+ *                                    descriptor kernel) instead of behind the whole previous call; 0: as before
  * Results never depend on an option (each setting is covered by a parity test); only speed does. */
 int sd_set_option(const char* name, int value);
 int sd_get_option(const char* name, int* value);

@@ -1355,6 +1355,7 @@ static int ensure_geometry(sd_orb* h, int w, int hgt) {
   SD_HIP_CHECK(hipStreamSynchronize(h->stream));
   { int rcw = wait_trackers(h); if (rcw != SD_OK) return rcw; }
   drop_graphs(h);
+  h->select_recorded = false;
   h->have_geom = false;
   h->cur_w = h->cur_h = 0;
   h->last_frames = 0;
@@ -1373,15 +1374,25 @@ static int ensure_geometry(sd_orb* h, int w, int hgt) {
 
 // The kernels of one extraction on the handle's three streams (main: pyramid chain, select, descriptors; fast: FAST per
 // level; aux: blur), forked and joined with events only -- also what gets captured into a hipGraph.
-static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, size_t frame_stride, bool prof, hipEvent_t* ev) {
+static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, size_t frame_stride, bool prof, hipEvent_t* ev,
+                         bool frames_ready, bool capturing) {
   const HostPlan& hp = h->hp;
   const OrbPlan& P = hp.plan;
   hipStream_t s = h->stream;
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[0], s));
   bool fast_started = false;
-  // the previous call's select (main stream) read d_cand / d_cell_count: FAST must not overwrite them early
-  SD_HIP_CHECK(hipEventRecord(h->ev_fast_done, s));
-  SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_fast_done, 0));
+  // The previous call's selection (main stream) read d_cand / d_cell_count: FAST must not overwrite them before it is done.
+  // r3: FAST of level 0 reads the caller's frames and needs nothing else of THIS call, so with frames that are already on the
+  // device (frames_ready: the device-input entry point) it is ordered behind the previous SELECTION only (ev_select_done)
+  // and runs beside the previous batch's descriptor kernel, a gather-latency-bound kernel that leaves the vector ALUs idle.
+  // Otherwise (host frames copied on this stream, a captured graph, option off, first call) behind everything queued so far.
+  const bool fast_early = frames_ready && !capturing && h->select_recorded && opt(OPT_FAST0_EARLY) != 0;
+  if (fast_early) {
+    SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_select_done, 0));
+    if (h->user_fence_live) SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_user_fence[1], 0));   // the upload of these frames
+  }
+  SD_HIP_CHECK(hipEventRecord(h->ev_body_start, s));
+  if (!fast_early) SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_body_start, 0));
   const bool src_aligned = (((uintptr_t)d_imgs | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) == 0;
   // FAST of level 0 reads the frames themselves when they are 4-byte aligned: it starts at once, beside the resize chain
   const bool fast0_direct = src_aligned && P.lv[0].ncells > 0 && opt(OPT_FAST0_FROM_FRAMES) != 0;
@@ -1479,6 +1490,10 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   // (also without any grid cell -- nfeatures so small that every level's levelCols is 0: the per-level counts the descriptor
   // kernel reads must still be written, as zeros)
   hipLaunchKernelGGL(k_select_final, dim3(P.nlevels, n), dim3(64), 0, s, h->d_plan, h->d_lvl_m, h->d_scratch, h->d_sel, h->d_sel_count);
+  if (!capturing) {   // d_cand / d_cell_count are free again: the next call's level-0 FAST may start (see the top of this function)
+    SD_HIP_CHECK(hipEventRecord(h->ev_select_done, s));
+    h->select_recorded = true;
+  }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[7], s));
   SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_blur_done, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[4], s));
@@ -1506,7 +1521,7 @@ static void drop_graphs(sd_orb* h) {
   }
 }
 
-static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, size_t frame_stride) {
+static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, size_t frame_stride, bool frames_ready) {
   hipStream_t s = h->stream;
   const bool prof = h->profiling;
   hipEvent_t* ev = h->ev[h->ev_calls % sd_orb::kRing];
@@ -1521,7 +1536,7 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   const bool use_graph = opt(OPT_USE_GRAPH) != 0;
   int rc = SD_OK;
   if (prof || !use_graph) {
-    rc = pipeline_body(h, d_imgs, n, stride, frame_stride, prof, ev);
+    rc = pipeline_body(h, d_imgs, n, stride, frame_stride, prof, ev, frames_ready, false);
   } else {
     sd_orb::GraphEntry* ge = nullptr;
     float dv[9] = {h->dist_K[0], h->dist_K[1], h->dist_K[2], h->dist_K[3], h->dist[0], h->dist[1], h->dist[2], h->dist[3], h->dist[4]};
@@ -1532,7 +1547,8 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
     if (!ge) {
       hipGraph_t graph = nullptr;
       SD_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      rc = pipeline_body(h, d_imgs, n, stride, frame_stride, false, ev);
+      rc = pipeline_body(h, d_imgs, n, stride, frame_stride, false, ev, false, true);
+      h->select_recorded = false;   // the graph's selection is not an event record a later call could wait for
       hipError_t e = hipStreamEndCapture(s, &graph);
       if (rc == SD_OK && e != hipSuccess) {
         set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -1673,6 +1689,8 @@ int sd_orb_create(int nfeatures, float scale_factor, int nlevels, int th_fast, i
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->fast_stream, hipStreamNonBlocking);
   for (int i = 0; i < SD_MAX_LEVELS && e == hipSuccess; i++) e = hipEventCreateWithFlags(&h->ev_level[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fast_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_select_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_body_start, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_pyr_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_blur_done, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -1707,6 +1725,8 @@ void sd_orb_destroy(sd_orb* h) {
   for (int i = 0; i < SD_MAX_LEVELS; i++)
     if (h->ev_level[i]) (void)hipEventDestroy(h->ev_level[i]);
   if (h->ev_fast_done) (void)hipEventDestroy(h->ev_fast_done);
+  if (h->ev_select_done) (void)hipEventDestroy(h->ev_select_done);
+  if (h->ev_body_start) (void)hipEventDestroy(h->ev_body_start);
   if (h->ev_pyr_done) (void)hipEventDestroy(h->ev_pyr_done);
   if (h->ev_blur_done) (void)hipEventDestroy(h->ev_blur_done);
   for (int i = 0; i < 2; i++)
@@ -1774,7 +1794,9 @@ int sd_orb_extract_batch_device(sd_orb* h, const void* d_imgs, int n_frames, int
   SD_HIP_CHECK(hipSetDevice(h->device));
   int rc = ensure_geometry(h, w, hgt);
   if (rc != SD_OK) return rc;
-  return launch_pipeline(h, (const uint8_t*)d_imgs, n_frames, stride, frame_stride);
+  // frames_ready: the caller's frames are complete on the device (or ordered by sd_orb_stream_fence); the host-input entry
+  // points copy them on the extraction stream and call launch_pipeline themselves
+  return launch_pipeline(h, (const uint8_t*)d_imgs, n_frames, stride, frame_stride, !h->staging_input);
 }
 
 int sd_orb_download(sd_orb* h, int frame0, int n_frames, sd_keypoint* kps_out, uint8_t* desc_out, int cap_per_frame,
@@ -1833,7 +1855,9 @@ int sd_orb_extract_batch(sd_orb* h, const uint8_t* imgs, int n_frames, int w, in
       SD_HIP_CHECK(hipMemcpy2DAsync(h->d_img + (size_t)f * w * hgt, w, imgs + (size_t)f * frame_stride, stride, w,
                                     (size_t)hgt, hipMemcpyHostToDevice, h->stream));
   }
+  h->staging_input = true;    // the frames reach d_img by a copy queued on the extraction stream just above
   int rc = sd_orb_extract_batch_device(h, h->d_img, n_frames, w, hgt, w, (size_t)w * hgt);
+  h->staging_input = false;
   if (rc != SD_OK) return rc;
   return sd_orb_download(h, 0, n_frames, kps_out, desc_out, cap_per_frame, n_out);
 }
@@ -1967,6 +1991,7 @@ int sd_orb_stream_fence(sd_orb* h, void* hip_stream, int direction) {
   } else {
     SD_HIP_CHECK(hipEventRecord(h->ev_user_fence[1], ext));
     SD_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_user_fence[1], 0));
+    h->user_fence_live = true;   // an early level-0 FAST launch (pipeline_body) waits for it as well
   }
   return SD_OK;
 }

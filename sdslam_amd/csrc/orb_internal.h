@@ -24,6 +24,8 @@ struct sd_orb {
   hipStream_t fast_stream = nullptr;
   hipEvent_t ev_level[SD_MAX_LEVELS] = {};
   hipEvent_t ev_fast_done = nullptr;
+  hipEvent_t ev_select_done = nullptr, ev_body_start = nullptr;   // end of a call's selection (d_cand free again) / start of a call on `stream`
+  bool select_recorded = false, user_fence_live = false, staging_input = false;
   // Output sets.  What a tracker reads (padded pyramid, keypoints, descriptors, counts) exists once
   // or -- after sd::orb_enable_double_buffer, which sd_track_create calls on its `cur` handle -- twice:
   // extraction alternates between the sets, so batch n+1 is extracted on `stream` while the tracker

@@ -29,6 +29,7 @@ static const OptDef kOpts[OPT_COUNT] = {
     {"track.pnp_grid_cap", 0, 0, 1 << 20},
     {"track.poseopt_waves", 0, 0, 4},
     {"track.match_split", 1, 0, 1},
+    {"extract.fast0_early", 1, 0, 1},
 };
 
 static std::atomic<int> g_val[OPT_COUNT];
