@@ -49,6 +49,8 @@ const char* sd_version(void);
  *                                    (6 KB of LDS per frame through the serial part); 0: the single 39-KB kernel
  *   extract.fast0_early        1     device-input extractions: FAST of level 0 starts behind the PREVIOUS call's selection (beside its
  *                                    descriptor kernel) instead of behind the whole previous call; 0: as before
+ *   extract.pyr_early          0     1: ... and, on an extractor with two output sets (one a tracker is attached to), the resize chain as
+ *                                    well, on the auxiliary stream in front of the blur (measured: loses 8 % with the PnP step)
  * Results never depend on an option (each setting is covered by a parity test); only speed does. */
 int sd_set_option(const char* name, int value);
 int sd_get_option(const char* name, int* value);

@@ -1379,7 +1379,6 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   const HostPlan& hp = h->hp;
   const OrbPlan& P = hp.plan;
   hipStream_t s = h->stream;
-  if (prof) SD_HIP_CHECK(hipEventRecord(ev[0], s));
   bool fast_started = false;
   // The previous call's selection (main stream) read d_cand / d_cell_count: FAST must not overwrite them before it is done.
   // r3: FAST of level 0 reads the caller's frames and needs nothing else of THIS call, so with frames that are already on the
@@ -1393,6 +1392,22 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   }
   SD_HIP_CHECK(hipEventRecord(h->ev_body_start, s));
   if (!fast_early) SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_body_start, 0));
+  // r3: with two output sets (a tracker is attached) the pyramid of this call goes into the set the previous call does NOT read,
+  // so the resize chain, too, may run beside the previous call's descriptor kernel -- on the auxiliary stream in front of the
+  // blur, which follows it anyway (a FIFTH stream lands on the hardware queue of the FAST stream and the two serialise: HIP
+  // spreads a process's streams over four hardware queues) -- behind the previous selection, the upload of the frames and the
+  // tracker's last read of that set (launch_pipeline); the FAST launches of levels 1... then follow level 0 without waiting for
+  // the descriptors to end (they were idle for 0.6 ms per step).  OFF by default: bit-exact (tests run it), but the full step with
+  // the PnP solve loses 8 % (172 k vs 194.6 k frames/s, three alternating runs) -- the tracking kernels of the previous batch
+  // then share the machine with two FAST launches instead of one; with TrackWithMotionModel it is even (187 k both).
+  const bool pyr_early = fast_early && h->nsets == 2 && opt(OPT_PYR_EARLY) != 0;
+  hipStream_t ps = pyr_early ? h->aux_stream : s;
+  if (prof && !pyr_early) SD_HIP_CHECK(hipEventRecord(ev[0], s));
+  if (pyr_early) {
+    SD_HIP_CHECK(hipStreamWaitEvent(ps, h->ev_select_done, 0));
+    if (h->user_fence_live) SD_HIP_CHECK(hipStreamWaitEvent(ps, h->ev_user_fence[1], 0));
+    if (prof) SD_HIP_CHECK(hipEventRecord(ev[0], ps));   // (the pyramid stage is timed on the stream it runs on)
+  }
   const bool src_aligned = (((uintptr_t)d_imgs | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) == 0;
   // FAST of level 0 reads the frames themselves when they are 4-byte aligned: it starts at once, beside the resize chain
   const bool fast0_direct = src_aligned && P.lv[0].ncells > 0 && opt(OPT_FAST0_FROM_FRAMES) != 0;
@@ -1418,14 +1433,14 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
     const bool split = L.w >= 16 && (l == 0 ? src_aligned : L.fast_resize != 0);
     if (!split) {   // generic single-pass kernel (exact-2x INTER_AREA levels, odd source alignment, tiny levels)
       dim3 grid((L.pstride + 255) / 256, (L.prows + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), n), block(64, 4, 1);
-      hipLaunchKernelGGL(k_pyr_level, grid, block, 0, s, L, S, (size_t)P.pyr_frame_bytes, l, d_imgs, stride, frame_stride, h->d_pyr);
+      hipLaunchKernelGGL(k_pyr_level, grid, block, 0, ps, L, S, (size_t)P.pyr_frame_bytes, l, d_imgs, stride, frame_stride, h->d_pyr);
     } else {
     auto magic = [](unsigned d) { return (unsigned)(0xFFFFFFFFull / d) + 1u; };   // e / d == umulhi(e, magic) for e < 2^31 / d
     const int G = (L.w - 1) / 4;
     const int T = 5 + (((L.w + 2 * SD_EDGE + 3) & ~3) - 20 - 4 * G) / 4;
     const int Hh = (L.prows + PYR_RPT - 1) / PYR_RPT;   // padded rows per row-slot of a thread
     const unsigned n_resize = (unsigned)(((size_t)Hh * G + 255) / 256), n_edges = (unsigned)(((size_t)L.prows * T + 255) / 256);
-    hipLaunchKernelGGL(k_pyr_split, dim3(n_resize + n_edges, n), dim3(256), 0, s, L, S, (size_t)P.pyr_frame_bytes, l, h->d_coef, d_imgs,
+    hipLaunchKernelGGL(k_pyr_split, dim3(n_resize + n_edges, n), dim3(256), 0, ps, L, S, (size_t)P.pyr_frame_bytes, l, h->d_coef, d_imgs,
                        stride, frame_stride, h->d_pyr, G, magic((unsigned)G), Hh, T, magic((unsigned)T), n_resize);
     }
     // FAST of this level starts now, on its own stream
@@ -1444,7 +1459,7 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
     }
     const int first = merged ? merge_from : l;
     if (ncl > 0 && !(l == 0 && fast0_direct)) {
-      SD_HIP_CHECK(hipEventRecord(h->ev_level[l], s));
+      SD_HIP_CHECK(hipEventRecord(h->ev_level[l], ps));
       SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_level[l], 0));
       if (prof && !fast_started) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
       fast_started = true;
@@ -1453,10 +1468,11 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
                          P.thFAST);
     }
   }
-  if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], s));
-  // blur on the auxiliary stream, beside FAST + selection
-  SD_HIP_CHECK(hipEventRecord(h->ev_pyr_done, s));
+  if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], ps));
+  // blur on the auxiliary stream, beside FAST + selection (d_blur exists once: behind the previous call's descriptors)
+  SD_HIP_CHECK(hipEventRecord(h->ev_pyr_done, ps));
   SD_HIP_CHECK(hipStreamWaitEvent(h->aux_stream, h->ev_pyr_done, 0));
+  if (pyr_early) SD_HIP_CHECK(hipStreamWaitEvent(h->aux_stream, h->ev_body_start, 0));
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[3], h->aux_stream));
   hipLaunchKernelGGL(k_blur, dim3((unsigned)hp.blur_tiles.size(), n), dim3(256), 0, h->aux_stream, h->d_plan, h->d_tiles, h->d_pyr,
                      h->d_blur, h->d_sel_count);
@@ -1529,6 +1545,7 @@ static int launch_pipeline(sd_orb* h, const uint8_t* d_imgs, int n, int stride, 
   select_set(h, (h->set + 1) % h->nsets);
   if (h->set_busy[h->set]) {
     SD_HIP_CHECK(hipStreamWaitEvent(s, h->ev_set_free[h->set], 0));
+    if (h->nsets == 2) SD_HIP_CHECK(hipStreamWaitEvent(h->aux_stream, h->ev_set_free[h->set], 0));   // (an early pyramid, pipeline_body)
     h->set_busy[h->set] = false;
   }
   // hipGraph replay is opt-in (option "extract.use_graph"): measured on ROCm 7.2 / MI355X the single-frame call takes 0.43 ms through

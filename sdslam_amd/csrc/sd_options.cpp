@@ -30,6 +30,7 @@ static const OptDef kOpts[OPT_COUNT] = {
     {"track.poseopt_waves", 0, 0, 4},
     {"track.match_split", 1, 0, 1},
     {"extract.fast0_early", 1, 0, 1},
+    {"extract.pyr_early", 0, 0, 1},
 };
 
 static std::atomic<int> g_val[OPT_COUNT];

@@ -89,6 +89,19 @@ def _compare(wl, ora, solver, rec_host):
 @pytest.mark.parametrize("pyramid", PYRAMIDS)
 @pytest.mark.parametrize("solver", ["pnp", "poseopt", "motion_model"])
 def test_bench_step_1024_frames_every_slot(scenes, oracle_steps, solver, pyramid, monkeypatch):
+    _bench_step_1024(scenes, oracle_steps, solver, pyramid, monkeypatch)
+
+
+@pytest.mark.parametrize("opts", [{"extract.fast0_early": 0}, {"extract.pyr_early": 1}, {"track.match_split": 0}],
+                         ids=["fast0_late", "pyr_early", "match_single"])
+def test_bench_step_1024_frames_scheduling_options(scenes, oracle_steps, opts, monkeypatch):
+    """The same 1024 slots under the non-default scheduling / kernel-form options: results never depend on an option."""
+    import sdslam_amd
+    with sdslam_amd.options(opts):
+        _bench_step_1024(scenes, oracle_steps, "pnp", "8x1.2", monkeypatch)
+
+
+def _bench_step_1024(scenes, oracle_steps, solver, pyramid, monkeypatch):
     import bench
     from sdslam_amd.capi import DeviceBuffer, lib, _p
     B = 1024

@@ -317,9 +317,18 @@ def test_epnp_device_vs_oracle(sd, oracle):
         assert np.abs(R - Rg).max() <= 1e-9 and np.abs(t - tg).max() <= 1e-9, (trial, n, np.abs(t - tg).max())
 
 
-def test_pipelined_steps_match_isolated_steps(sd, oracle):
+@pytest.mark.parametrize("opts", [{}, {"extract.fast0_early": 0}, {"extract.pyr_early": 1}, {"track.align_start": 0}, {"track.align_start": 1}],
+                         ids=["default", "fast0_late", "pyr_early", "align_after_extraction", "align_after_pyramid"])
+def test_pipelined_steps_match_isolated_steps(sd, oracle, opts):
     """Back-to-back steps without host synchronisation (extraction of batch n+1 overlaps tracking of batch n on
-    the double-buffered extractor) give exactly the results of the same steps run one at a time."""
+    the double-buffered extractor; level-0 FAST -- and optionally the resize chain -- of batch n+1 start behind the
+    SELECTION of batch n, beside its descriptors) give exactly the results of the same steps run one at a time, under
+    every setting of the scheduling options."""
+    with sd.options(opts):
+        _pipelined_vs_isolated(sd)
+
+
+def _pipelined_vs_isolated(sd):
     B = 4
     scenes_a = [synth.make_scene(60 + i, (0.02, -0.01, 0.015), (0.4, -0.3, 0.5)) for i in range(B)]
     scenes_b = [synth.make_scene(70 + i, (-0.02, 0.02, -0.01), (-0.5, 0.2, 0.3)) for i in range(B)]
