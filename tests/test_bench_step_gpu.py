@@ -149,7 +149,8 @@ def test_tracking_step_1280x720(oracle_steps):
         assert all(o["al"]["ok"] for o in ora) and min(o["nm"] for o in ora) >= 100
 
 
-def test_bench_two_ranks_rehearsal():
+@pytest.mark.parametrize("shape", ["vga_b64", "configs4_shard"])
+def test_bench_two_ranks_rehearsal(shape):
     """bench.py's N > 1 control flow on this one-GPU box: `--gpus 2` spawns two ranks (both on GPU 0, gloo over host memory:
     SD_BENCH_REHEARSAL), every step packs the records on the device and gathers them inside the timed region, rank 0 checks
     its own block of the gathered tensor against its records and prints one line.  (The RCCL leg itself -- device tensors
@@ -163,9 +164,11 @@ def test_bench_two_ranks_rehearsal():
     env = dict(os.environ, SD_BENCH_REHEARSAL="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "64",
-                        "--unique", "4", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    # configs4_shard: the exact per-rank workload of BASELINE configs[4] on 8 GPUs (8192 x 1280x720 frames / 8 = 1024 per rank)
+    B, extra = (64, []) if shape == "vga_b64" else (1024, ["--res", "1280x720"])
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", str(B),
+                        "--unique", "4", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["frames_per_gpu_per_step"] == 64 and "REHEARSAL" in line["config"]["pose_records"]
-    assert line["tracking"]["pnp_ok"] == 64 and line["value"] > 0
+    assert line["n_gpus"] == 2 and line["config"]["frames_per_gpu_per_step"] == B and "REHEARSAL" in line["config"]["pose_records"]
+    assert line["tracking"]["pnp_ok"] == B and line["value"] > 0
