@@ -42,6 +42,27 @@ void set_error(const std::string& msg) { g_err = msg; }
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
+// Frame / block of this workgroup for a (blocks, frames) grid such that the workgroups of ONE frame run on ONE XCD: the dispatcher
+// deals workgroups to the 8 XCDs round-robin in linear order (MI355X_MICROARCH.md, workgroup dispatch), every XCD has its own 4-MB L2,
+// and the workgroups of a frame re-read each other's rows (resize: the two source rows of adjacent output rows; FAST / blur: tile
+// halos; 128-B lines shared by neighbouring tiles).  Bijective for any grid size; a speed choice only.
+#ifndef SD_XCD_REMAP
+#define SD_XCD_REMAP 1
+#endif
+__device__ __forceinline__ void xcd_frame_block(unsigned& frame, unsigned& blk) {
+#if SD_XCD_REMAP
+  const unsigned nx = gridDim.x, total = nx * gridDim.y;
+  const unsigned lin = blockIdx.y * nx + blockIdx.x;
+  const unsigned q = total >> 3, r = total & 7u, xcd = lin & 7u;
+  const unsigned logical = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (lin >> 3);
+  frame = logical / nx;
+  blk = logical - frame * nx;
+#else
+  frame = blockIdx.y;
+  blk = blockIdx.x;
+#endif
+}
+
 __device__ __forceinline__ int reflect101(int p, int len) {
   if ((unsigned)p < (unsigned)len) return p;
   if (len == 1) return 0;
@@ -374,13 +395,15 @@ __global__ __launch_bounds__(256) void k_pyr_split(const LevelGeom L, const Leve
                                                    const int32_t* __restrict__ coef, const uint8_t* __restrict__ src0, int src_stride,
                                                    size_t src_frame_stride, uint8_t* __restrict__ pyr, int G, unsigned magicG, int Hh,
                                                    int T, unsigned magicT, unsigned n_resize) {
-  const int frame = blockIdx.y;
-  if (blockIdx.x < n_resize)
+  unsigned uframe, bx;
+  xcd_frame_block(uframe, bx);
+  const int frame = (int)uframe;
+  if (bx < n_resize)
     pyr_resize_body(L, S, pyr_frame_bytes, level, coef, src0, src_stride, src_frame_stride, pyr, G, magicG, Hh, frame,
-                    blockIdx.x * 256 + threadIdx.x);
+                    bx * 256 + threadIdx.x);
   else
     pyr_edges_body(L, S, pyr_frame_bytes, level, src0, src_stride, src_frame_stride, pyr, G, T, magicT, frame,
-                   (blockIdx.x - n_resize) * 256 + threadIdx.x);
+                   (bx - n_resize) * 256 + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -519,8 +542,8 @@ __device__ unsigned long long g_fast_prof_wg[(size_t)FPROF_FRAMES * FPROF_CELLS 
   } while (0)
 #define FPROF_FLUSH                                                                                                   \
   do {                                                                                                                \
-    if (threadIdx.x == 0 && blockIdx.y < FPROF_FRAMES && cell < FPROF_CELLS)                                          \
-      for (int _i = 0; _i < 8; _i++) g_fast_prof_wg[((size_t)blockIdx.y * FPROF_CELLS + cell) * 8 + _i] = s_fprof[_i]; \
+    if (threadIdx.x == 0 && frame < FPROF_FRAMES && cell < FPROF_CELLS)                                          \
+      for (int _i = 0; _i < 8; _i++) g_fast_prof_wg[((size_t)frame * FPROF_CELLS + cell) * 8 + _i] = s_fprof[_i]; \
   } while (0)
 #else
 #define FPROF_DECL
@@ -562,9 +585,11 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
                                                     int cell0, int th) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int wcnt[4];
-  const int cell = blockIdx.x + cell0;   // launched per level: the cells of a level are contiguous
+  unsigned uframe, ucell;
+  xcd_frame_block(uframe, ucell);
+  const int cell = (int)ucell + cell0;   // launched per level: the cells of a level are contiguous
   const CellGeom C = cells[cell];
-  const int frame = blockIdx.y;
+  const int frame = (int)uframe;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (C.zw <= 0 || C.zh <= 0) {
     if (tid == 0) cell_count[(size_t)frame * ncells_total + cell] = 0;
@@ -936,8 +961,10 @@ __global__ __launch_bounds__(64) void k_select_final(const OrbPlan* __restrict__
 __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, const BlurTile* __restrict__ tiles,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                               const int32_t* __restrict__ sel_count) {
-  const BlurTile T = tiles[blockIdx.x];
-  const int frame = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned uframe, utile;
+  xcd_frame_block(uframe, utile);
+  const BlurTile T = tiles[utile];
+  const int frame = (int)uframe, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   (void)sel_count;   // every level is blurred: the stage then depends on the pyramid only and overlaps FAST/selection
   const LevelGeom L = P->lv[T.level];
   const int x0 = T.tx * BLUR_TW + lane * 4;

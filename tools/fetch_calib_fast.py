@@ -78,5 +78,31 @@ for name in launches:
 tot_raw = sum(o.get("FETCH_SIZE_bytes_raw", 0) for o in out.values())
 tot_u = sum(o["unique_bytes_per_launch"] for o in out.values())
 out["all FAST launches of a step"] = {"unique_bytes": tot_u, "FETCH_SIZE_bytes_raw": tot_raw, "raw_over_unique": tot_raw / tot_u, "x2_over_unique": 2 * tot_raw / tot_u}
+# ---- the pyramid (k_pyr_split, one launch per level in level order): unique bytes read by launch l = the interior of its
+# source (the caller's frame for level 0, level l-1 of the padded pyramid otherwise); every border pixel is computed from the same
+# source rows / columns.  Written: the padded level (64-B aligned rows).
+pdisp = []
+for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_pyr_split" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+            pdisp.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]) * 1024.0))
+pdisp.sort()
+NL = CFG[2]
+prow = defaultdict(list)
+for k, (_, v) in enumerate(pdisp):
+    prow[k % NL].append(v)
+ptot_raw = ptot_u = 0
+for l in range(NL):
+    sw, sh = (W, H) if l == 0 else (int(info["levels"][l - 1, 0]), int(info["levels"][l - 1, 1]))
+    u = sw * sh * B
+    if prow[l]:
+        raw = float(np.mean(prow[l]))
+        out[f"pyramid level {l} (k_pyr_split)"] = {"unique_source_bytes_per_launch": u, "launches_seen": len(prow[l]), "FETCH_SIZE_bytes_raw": raw,
+                                                   "raw_over_unique": raw / u, "x2_over_unique": 2 * raw / u}
+        ptot_raw += raw
+        ptot_u += u
+if ptot_u:
+    out["all pyramid launches of a step"] = {"unique_source_bytes": ptot_u, "FETCH_SIZE_bytes_raw": ptot_raw, "raw_over_unique": ptot_raw / ptot_u,
+                                             "x2_over_unique": 2 * ptot_raw / ptot_u}
 json.dump(out, sys.stdout, indent=1)
 print()

@@ -16,8 +16,12 @@ import sys
 from collections import defaultdict
 
 
-# FETCH_SIZE calibration factor per kernel (default 2: wide / coalesced streams)
-CAL = {"k_fast_cells": 1.0}
+# FETCH_SIZE calibration factor per kernel (default 2).  Rounds 1-2 used 1.0 for k_fast_cells (a stand-in stream with the FAST
+# tile shape read 1.12 x its unique bytes uncorrected); round 3 showed that reading to be wrong: with the workgroups of a frame
+# kept on one XCD (orb.hip xcd_frame_block) the REAL launches read 0.59 x their unique bytes uncorrected -- impossible -- and
+# 1.19 x with the guide's x2 (profiles/r03c_fetch_calibration.json).  The stand-in, like the kernel, had been re-reading every
+# tile halo / shared 128-B line once per XCD.
+CAL = {}
 
 
 def short(name):
@@ -49,10 +53,8 @@ def main():
             e[c + "_samples"] = cnt[k][c]
         if "FETCH_SIZE_per_launch" in e:
             # rocprofv3's FETCH_SIZE tallies every EA read request at 64 B (its 128-B term, TCC_BUBBLE, stays 0 on gfx950):
-            # streams of full 128-B requests read exactly half (x2: MI355X_MICROARCH.md, re-measured for dwordx4 AND plain dword
-            # coalesced loads: profiles/r02_fetch_calibration.json); short unaligned row segments (the FAST tile staging: 132-B
-            # rows at a 768-B pitch) go out as 64-B requests and read the true byte count (x1).  Both are reported; the
-            # per-kernel choice is CAL below (calibrated with tools/valu_microbench --stream).
+            # x2 (MI355X_MICROARCH.md; re-measured for dwordx4 and plain dword streams, profiles/r02_fetch_calibration.json, and
+            # on the real FAST / pyramid launches, profiles/r03c_fetch_calibration.json).  Raw and x2 are both reported.
             raw = e["FETCH_SIZE_per_launch"] * 1024
             e["FETCH_bytes_raw_per_launch"] = raw
             e["FETCH_bytes_x2_per_launch"] = raw * 2
