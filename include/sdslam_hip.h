@@ -43,7 +43,6 @@ const char* sd_version(void);
  *                                    2: after its pyramid and FAST launches (beside selection + descriptors)
  *   track.align_min_waves      5     register budget of k_align in waves per SIMD (3, 4, 5)
  *   track.bf_list_k            4     SearchByPoints: keys kept per point, 1..4 -- tests force the whole-row recomputation
- *   track.pnp_grid_cap         0     >0: k_pnp walks the frames with at most this many workgroups
  *   track.poseopt_waves        0     k_pose_opt waves per frame: 0 = by batch size (4 up to 256 frames, else 1), 1, 4
  *   track.match_split          1     SearchByProjection(Frame, Frame / KeyFrame) as candidate + one-wave assignment kernels
  *                                    (6 KB of LDS per frame through the serial part); 0: the single 39-KB kernel

@@ -32,7 +32,7 @@ void set_error(const std::string& msg);
 // Process-wide options (sd_set_option / sd_get_option, sd_options.cpp; documented in include/sdslam_hip.h).
 enum Opt {
   OPT_FAST0_FROM_FRAMES, OPT_USE_GRAPH, OPT_SELECT_SMALL_CAP, OPT_SELECT_BIG_CAP, OPT_FAST_MERGE_FROM, OPT_FAST_LDS_KB,
-  OPT_FAST_LDS_WHOLE_KB, OPT_TRACK_PRIORITY, OPT_ALIGN_START, OPT_ALIGN_MIN_WAVES, OPT_BF_LIST_K, OPT_PNP_GRID_CAP,
+  OPT_FAST_LDS_WHOLE_KB, OPT_TRACK_PRIORITY, OPT_ALIGN_START, OPT_ALIGN_MIN_WAVES, OPT_BF_LIST_K,
   OPT_POSEOPT_WAVES, OPT_MATCH_SPLIT, OPT_FAST0_EARLY, OPT_PYR_EARLY, OPT_COUNT
 };
 int opt(Opt o);

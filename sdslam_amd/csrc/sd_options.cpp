@@ -26,7 +26,6 @@ static const OptDef kOpts[OPT_COUNT] = {
     {"track.align_start", 2, 0, 2},
     {"track.align_min_waves", 5, 3, 5},
     {"track.bf_list_k", 4, 1, 4},
-    {"track.pnp_grid_cap", 0, 0, 1 << 20},
     {"track.poseopt_waves", 0, 0, 4},
     {"track.match_split", 1, 0, 1},
     {"extract.fast0_early", 1, 0, 1},

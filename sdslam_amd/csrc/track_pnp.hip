@@ -54,6 +54,15 @@ __device__ unsigned long long g_pnp_prof[32];
 #define PROF(i)
 #endif
 
+// The solvers below are real calls (one instruction stream per routine; inlining them all leaves the register allocator with
+// > 500 live VGPRs).  A device function does not inherit its kernel's launch bounds: left alone it is compiled for the default
+// 1024-thread workgroup, i.e. a 128-VGPR budget, and the unrolled fp64 Jacobi / QR bodies then spill inside their loops (r2: 2.1 KB
+// of scratch per lane, 120 MB of scratch writes per launch).  k_pnp runs one 64-lane wave per frame at one wave per SIMD, so its
+// callees get that kernel's budget stated explicitly.
+#ifndef PNP_FN
+#define PNP_FN static __noinline__ __attribute__((disable_tail_calls))
+#endif
+
 // LDS pointers keep their address space (ds_read / ds_write); through a generic double* every access
 // becomes a flat_load that waits on both the LDS and the global counters.
 typedef __attribute__((address_space(3))) double ldsd;
@@ -73,7 +82,7 @@ struct LArr {
 // Tail of JacobiSVDImpl_ for the 12 x 12 case (final norms, descending selection sort of the rows,
 // normalisation / zero-singular-value fill-in), matrix and W in (lane-interleaved) LDS.
 template <typename Ptr>
-__device__ __noinline__ void jacobi_finish12(Ptr At, Ptr W) {
+__device__ PNP_FN void jacobi_finish12(Ptr At, Ptr W) {
   const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
   constexpr int m = 12, n = 12;
   int i, j, k, iter;
@@ -146,7 +155,7 @@ __device__ __noinline__ void jacobi_finish12(Ptr At, Ptr W) {
 
 // Zero-singular-value fill-in of row i (JacobiSVDImpl_'s tail): rare, so it stays generic and
 // works on a private-memory copy.  Returns the row's new norm.
-__device__ __noinline__ double jacobi_fill_row(double* At, int astep, int m, int i, unsigned long long* rng_io, double sd) {
+__device__ PNP_FN double jacobi_fill_row(double* At, int astep, int m, int i, unsigned long long* rng_io, double sd) {
   const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
   unsigned long long rng = *rng_io;
   for (int ii = 0; ii < 100 && sd <= minval; ii++) {
@@ -346,7 +355,7 @@ __device__ __forceinline__ bool jacobi_pair12(Ptr A, Ptr W, int i, int j) {
 // g < 6 of a matrix takes the g-th pair of the step; `act` = this lane's matrix exists.  A matrix whose sweep rotated
 // nothing is finished (the sequential loop's `break`).
 template <typename Ptr>
-__device__ __noinline__ void jacobi_sweeps12_coop(Ptr A, Ptr W, int g, bool act, unsigned long long group_mask) {
+__device__ PNP_FN void jacobi_sweeps12_coop(Ptr A, Ptr W, int g, bool act, unsigned long long group_mask) {
   if (act && g < 6)
     for (int i = g; i < 12; i += 6) {
       double sd = 0;
@@ -391,38 +400,6 @@ __device__ __forceinline__ void svd3(const double* A, double* W, double* Ut, dou
   }
 }
 
-// cvSolve(A (6 x N), b, x, CV_SVD); A row-major with row stride N
-template <int N>
-__device__ __noinline__ void solve_svd6(const double* A, const double* b, double* x) {
-  double a[N][6], v[N][N], w[N];
-#pragma unroll
-  for (int i = 0; i < N; i++)
-#pragma unroll
-    for (int j = 0; j < 6; j++) a[i][j] = A[j * N + i];
-  jacobi_svd_small<6, N>(a, w, v);
-  double xr[N];
-#pragma unroll
-  for (int i = 0; i < N; i++) xr[i] = 0;
-  double threshold = 0;
-#pragma unroll
-  for (int i = 0; i < N; i++) threshold += w[i];
-  threshold *= DBL_EPSILON * 2;
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    double wi = w[i];
-    if (fabs(wi) <= threshold) continue;
-    wi = 1 / wi;
-    double s = 0;
-#pragma unroll
-    for (int j = 0; j < 6; j++) s += a[i][j] * b[j];
-    s *= wi;
-#pragma unroll
-    for (int j = 0; j < N; j++) xr[j] = xr[j] + s * v[i][j];
-  }
-#pragma unroll
-  for (int i = 0; i < N; i++) x[i] = xr[i];
-}
-
 // The three find_betas variants solve 6 x 4, 6 x 3 and 6 x 5 systems on three lanes of ONE wave: as three template
 // instantiations they are three instruction streams that the wave executes one after the other (each with one lane active).
 // This is the same one-sided Jacobi SVD + back-substitution with the column count N as a per-lane RUN-TIME value on a
@@ -430,14 +407,17 @@ __device__ __noinline__ void solve_svd6(const double* A, const double* b, double
 // instruction stream and run side by side.  The operations a lane performs on its real rows, and their order, are exactly
 // those of jacobi_svd_small<6, N> / solve_svd6<N> (the pairs (i, j), i < j < N, of the 5-row cyclic order are the N-row
 // cyclic order; a sweep over a converged matrix rotates nothing), so the results are bit-identical.
-__device__ __noinline__ void solve_svd6_n(int N, const double* A /* 6 x N row-major */, const double* b, double* x) {
+// r3: A is read where it lies -- column i of the system is column col[i] of the 6 x 10 matrix L in LDS (the variant's choice of
+// find_betas_approx_{1,2,3}) -- and b / x are registers of the (inlining) caller: nothing goes through private memory.
+template <typename Ptr>
+__device__ __forceinline__ void solve_svd6_n(int N, Ptr L, const int (&col)[5], const double (&b)[6], double (&x)[5]) {
   constexpr int M = 6, NM = 5;
   const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
   double At[NM][M], Vt[NM][NM], W[NM];
 #pragma unroll
   for (int i = 0; i < NM; i++) {
 #pragma unroll
-    for (int j = 0; j < M; j++) At[i][j] = i < N ? A[j * N + i] : 0.0;
+    for (int j = 0; j < M; j++) At[i][j] = i < N ? L[10 * j + col[i]] : 0.0;
     double sd = 0;
 #pragma unroll
     for (int k = 0; k < M; k++) sd += At[i][k] * At[i][k];
@@ -568,8 +548,7 @@ __device__ __noinline__ void solve_svd6_n(int N, const double* A /* 6 x N row-ma
     }
   }
 #pragma unroll
-  for (int i = 0; i < NM; i++)
-    if (i < N) x[i] = xr[i];
+  for (int i = 0; i < NM; i++) x[i] = i < N ? xr[i] : 0.0;
 }
 
 __device__ void invert_svd3(const double* A, double* Ainv) {
@@ -596,7 +575,7 @@ __device__ __forceinline__ double dist2_3(const double* p1, const double* p2) {
 // 6 x 4 Householder QR solve (src/PnPsolver.cc:812-901) with every index a compile-time constant
 // (registers).  NB the reference's pivot search reads rows k .. nr-2 (it re-reads A[k][k] and never
 // looks at the last row); that is kept.  A is row-major 6 x 4.
-__device__ __noinline__ void qr_solve64(double* pA, double* pb, double* pX) {
+__device__ __forceinline__ void qr_solve64(const double (&pA)[24], const double (&pb)[6], double (&pX)[4]) {
   constexpr int nr = 6, nc = 4;
   double A[nr][nc], b[nr], A1[nc], A2[nc];
 #pragma unroll
@@ -721,27 +700,21 @@ __device__ void epnp_L_rho(Ptr ut, const double cws[4][3], Ptr L, double rho[6],
 
 // find_betas_approx_{1,2,3} followed by gauss_newton (5 iterations).  The three variants depend
 // only on L and rho, never on each other, so they run on three lanes side by side.
+struct Rho6 { double r[6]; };
+struct Betas4 { double b[4]; };
+// r3: L stays in LDS, rho arrives and the betas leave BY VALUE (registers), the 6 x N least-squares solve and the five Gauss-Newton
+// QR solves are inlined here: the routine is a leaf with no operand in private memory (r2: l[30], a[24], b[6], x[4], bs[5] written to
+// scratch for the callees to read back, 205 doubles per call).
 template <typename Ptr>
-__device__ __noinline__ void epnp_betas(int variant, Ptr L, const double* rho, double betas[4]) {
+__device__ PNP_FN void epnp_betas(int variant, Ptr L, const Rho6 rho_v, Betas4& out) {
   PROF_DECL;
   // find_betas_approx_{1,2,3} (src/PnPsolver.cc:700-780): the variant picks its columns of L, one shared solver
   const int N = variant == 1 ? 4 : (variant == 2 ? 3 : 5);
-  double l[30], bs[5] = {0, 0, 0, 0, 0};
-  for (int i = 0; i < 6; i++) {
-    if (variant == 1) {
-      l[4 * i] = L[10 * i];
-      l[4 * i + 1] = L[10 * i + 1];
-      l[4 * i + 2] = L[10 * i + 3];
-      l[4 * i + 3] = L[10 * i + 6];
-    } else if (variant == 2) {
-      l[3 * i] = L[10 * i];
-      l[3 * i + 1] = L[10 * i + 1];
-      l[3 * i + 2] = L[10 * i + 2];
-    } else {
-      for (int j = 0; j < 5; j++) l[5 * i + j] = L[10 * i + j];
-    }
-  }
-  solve_svd6_n(N, l, rho, bs);
+  const int col[5] = {0, 1, variant == 1 ? 3 : 2, variant == 1 ? 6 : 3, 4};
+  double rho[6], bs[5], betas[4];
+#pragma unroll
+  for (int i = 0; i < 6; i++) rho[i] = rho_v.r[i];
+  solve_svd6_n(N, L, col, rho, bs);
   if (variant == 1) {
     if (bs[0] < 0) {
       betas[0] = sqrt(-bs[0]);
@@ -796,6 +769,8 @@ __device__ __noinline__ void epnp_betas(int variant, Ptr L, const double* rho, d
     for (int i = 0; i < 4; i++) betas[i] += x[i];
   }
   PROF(6);
+#pragma unroll
+  for (int i = 0; i < 4; i++) out.b[i] = betas[i];
 }
 
 // compute_ccs
@@ -844,14 +819,19 @@ __device__ __forceinline__ double epnp_reproj_term(const double Rv[3][3], const 
 // per hypothesis run the 12 x 12 Jacobi sweeps (jacobi_sweeps12_coop), the variant-1 lane finishes the SVD
 // and writes L into the hypothesis' LDS view, then each lane follows its own
 // find_betas variant / Gauss-Newton / R,t / reprojection error.  Returns that variant's error.
-template <typename Ptr>
-__device__ __noinline__ double epnp_minimal(bool active, int variant, const double* pws, const double* us, const EpnpCam cam,
-                                            double Rv[3][3], double tv[3], Ptr ut, Ptr L, ldsd* Mrows /* PNP_CHUNK x 4 x 24 */,
-                                            int nhyp /* hypotheses in flight: lanes h < nhyp are active */) {
+// r3: inlined into its one caller; the four correspondences are fetched by `gather(k, pw, u)` where they lie (twice: they are not
+// kept across the find_betas call), and the barycentric coordinates wait in the lane's slot of the (by then idle) M-row scratch
+// area while epnp_betas runs -- that call uses the whole register file, and what is alive across it would otherwise go to scratch.
+template <typename Ptr, typename G>
+__device__ __forceinline__ double epnp_minimal(bool active, int variant, G&& gather, const EpnpCam cam, double (&Rv)[3][3],
+                                               double (&tv)[3], Ptr ut, Ptr L, ldsd* Mrows /* PNP_CHUNK x 4 x 24 */,
+                                               int nhyp /* hypotheses in flight: lanes h < nhyp are active */) {
   constexpr int n = 4;
   double cws[4][3], alphas[16], rho[6];
+  double pws[12], us[8];
   PROF_DECL;
   if (active) {
+    for (int k = 0; k < n; k++) gather(k, pws + 3 * k, us + 2 * k);
     cws[0][0] = cws[0][1] = cws[0][2] = 0;
     for (int i = 0; i < n; i++)
       for (int j = 0; j < 3; j++) cws[0][j] += pws[3 * i + j];
@@ -925,9 +905,23 @@ __device__ __noinline__ double epnp_minimal(bool active, int variant, const doub
   PROF(4);
   __syncthreads();   // ut / L of every hypothesis visible to its variant lanes
   double err = 0;
+  ldsd* park = Mrows + (threadIdx.x & 63) * 16;   // 3 * PNP_CHUNK lanes x 16 doubles <= PNP_CHUNK x 4 x 24 (the M rows were consumed above)
+  static_assert(3 * 16 <= 4 * 24, "alpha parking area");
   if (active) {
+    for (int i = 0; i < 16; i++) park[i] = alphas[i];
     double betas[4], ccs[4][3], pcs[12];
-    epnp_betas(variant, L, rho, betas);
+    {
+      Rho6 rv;
+      for (int i = 0; i < 6; i++) rv.r[i] = rho[i];
+      Betas4 bt;
+      epnp_betas(variant, L, rv, bt);
+      for (int i = 0; i < 4; i++) betas[i] = bt.b[i];
+    }
+    // the compiler knows that epnp_betas touches nothing but its arguments and would carry the values below across the call in
+    // registers (i.e. in scratch): make it read them again
+    asm volatile("" ::: "memory");
+    for (int i = 0; i < 16; i++) alphas[i] = park[i];
+    for (int k = 0; k < n; k++) gather(k, pws + 3 * k, us + 2 * k);
     PROF(9);   // (timed inside: slots 5 / 6)
     epnp_ccs(ut, betas, ccs);
     for (int i = 0; i < n; i++) {
@@ -1009,7 +1003,7 @@ __device__ __forceinline__ void ordered_sums(int n, ldsd* terms, ldsd* out, F&& 
 // alphas[] / pcs[] arrays (same expressions on the same inputs: same bits).  Round 2 kept all four as double arrays in HBM:
 // 96 bytes written and re-read several times per inlier, a third of the kernel's 19 x algorithmic traffic.
 template <typename Ptr, typename TIn>
-__device__ __noinline__ double epnp_refit_wave(int n, const TIn* pws, const TIn* us, const EpnpCam cam, ldsd* Rt_out, Ptr ut, Ptr L,
+__device__ PNP_FN void epnp_refit_wave(int n, const TIn* pws, const TIn* us, const EpnpCam cam, ldsd* Rt_out, Ptr ut, Ptr L,
                                                ldsd* terms, ldsd* red, ldsd* mtm) {
   const int lane = threadIdx.x & 63;
   double cws[4][3], ci[9];
@@ -1037,6 +1031,7 @@ __device__ __noinline__ double epnp_refit_wave(int n, const TIn* pws, const TIn*
       red[16 + i] = cws[1 + i / 3][i % 3];
       red[32 + i] = ci[i];
     }
+    for (int j = 0; j < 3; j++) red[48 + j] = cws[0][j];
   }
   __syncthreads();
   for (int i = 0; i < 9; i++) {
@@ -1108,11 +1103,18 @@ __device__ __noinline__ double epnp_refit_wave(int n, const TIn* pws, const TIn*
   __syncthreads();
   PROF(20);
   if (lane < 3) {
-    double betas[4];
-    epnp_betas(lane + 1, L, rho, betas);
-    for (int i = 0; i < 4; i++) red[4 * lane + i] = betas[i];
+    Rho6 rv;
+    for (int i = 0; i < 6; i++) rv.r[i] = rho[i];
+    Betas4 bt;
+    epnp_betas(lane + 1, L, rv, bt);
+    for (int i = 0; i < 4; i++) red[4 * lane + i] = bt.b[i];
   }
   __syncthreads();
+  // control points and their inverse again from LDS (slots untouched since they were broadcast): nothing of them stays in
+  // registers across the epnp_betas call, which uses the whole register file
+  asm volatile("" ::: "memory");
+  for (int i = 0; i < 12; i++) cws[i / 3][i % 3] = red[i < 3 ? 48 + i : 13 + i];
+  for (int i = 0; i < 9; i++) ci[i] = red[32 + i];
   double betas3[3][4];
   for (int i = 0; i < 12; i++) betas3[i / 4][i % 4] = red[i];
   __syncthreads();
@@ -1187,9 +1189,10 @@ __device__ __noinline__ double epnp_refit_wave(int n, const TIn* pws, const TIn*
   if (lane == 0) {
     for (int i = 0; i < 9; i++) Rt_out[i] = bestR[i / 3][i % 3];
     for (int i = 0; i < 3; i++) Rt_out[9 + i] = bestT[i];
+    red[63] = best_err;   // the reprojection error of the winner (a function that RETURNS a value keeps the callee-saved
+                          // register convention: 108 VGPRs saved and restored per call; a void one with local linkage does not)
   }
   __syncthreads();
-  return best_err;
 }
 
 // CheckInliers for correspondence i under (R, t): src/PnPsolver.cc:289-315
@@ -1208,7 +1211,10 @@ __device__ __forceinline__ bool pnp_is_inlier(const double* Rt, const float* q /
   return error2 < maxErr;
 }
 
-__global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all,
+// kGeneral: minimal sets of a size other than 4 (one hypothesis at a time through the wave-cooperative solver); the reference only ever
+// constructs 4 (src/PnPsolver.h:74).  Two instantiations: the common kernel then carries neither that path's call site nor its state.
+template <bool kGeneral>
+__global__ __launch_bounds__(64, 2) __attribute__((disable_tail_calls)) void k_pnp(const sd_keypoint* __restrict__ kps_all, const int32_t* __restrict__ nkp_all,
                                             TrackBuffers tb, TrackCam tcam, const float* __restrict__ sigma2, PnpParams pp,
                                             int n_frames) {
   // gathered correspondences live in HBM (read-mostly, L2-resident): {u, v, X, Y, Z, maxErr} f32
@@ -1218,6 +1224,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
   __shared__ unsigned long long s_best[PNP_WORDS], s_ref[PNP_WORDS];
   __shared__ int s_cnt[PNP_CHUNK];
   __shared__ double s_RtRef[12];
+  __shared__ float s_bestT[12];
   // One scratch area for two call-local uses (one wave per workgroup, the calls are sequential): the rows of M of the chunk's
   // minimal sets inside epnp_minimal, and the ordered-sum terms / MtM / reduction slots inside epnp_refit_wave.  Keeping them
   // apart cost 6 KB of the 30 KB this kernel holds per frame -- four frames per CU, beside k_fast_cells workgroups of 24-39 KB.
@@ -1229,9 +1236,11 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
   double* const s_red = s_scr + 64 * 9 + 144;
   __shared__ int s_modp[PNP_MAXSET], s_modv[PNP_MAXSET], s_draw[PNP_MAXSET];   // general minimal sets (mRansacMinSet != 4)
   const int lane = threadIdx.x;
-  // persistent waves: the grid may be smaller than the batch (launch_pnp)
-  for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
-  __syncthreads();
+  // one wave per frame.  (r2 walked the frames with a persistent loop for a capped-grid experiment, "track.pnp_grid_cap": the
+  // compiler hoisted everything invariant in that loop -- log / pow of the RANSAC parameters, the constants of the fp64 division
+  // and square-root expansions -- to the kernel entry and kept it alive, i.e. in scratch, across every call below.)
+  const int f = blockIdx.x;
+  if (f >= n_frames) return;
   const int cap = tb.kp_cap;
   const int fc = tb.cur_bcast >= 0 ? tb.cur_bcast : f;   // current-frame slot (TrackBuffers::cur_bcast)
   const sd_keypoint* kps = kps_all + (size_t)fc * cap;
@@ -1306,7 +1315,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
       info[2] = 1;   // bNoMore
       info[3] = pp.resume ? tb.pnp_state[(size_t)f * 4] : 0;
     }
-    continue;
+    return;
   }
   // ---- solver state that outlives an iterate() call (src/PnPsolver.h: mnIterations, mnBestInliers, mvbBestInliers,
   // mBestTcw); refine_ok = what Refine() returns for the CURRENT best set (it is a pure function of that set)
@@ -1315,13 +1324,12 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
   float* st_T = tb.pnp_best_T + (size_t)f * 12;
   const int nwords = (N + 63) >> 6;
   int start = 0, best = 0, refine_ok = 0;
-  float bestT[12];
-  for (int i = 0; i < 12; i++) bestT[i] = 0.f;
+  if (lane < 12) s_bestT[lane] = 0.f;   // mBestTcw (LDS: twelve floats per lane would live across every solver call)
   if (pp.resume) {
     start = st[0];
     best = st[1];
     refine_ok = st[2];
-    for (int i = 0; i < 12; i++) bestT[i] = st_T[i];
+    if (lane < 12) s_bestT[lane] = st_T[lane];
     for (int w = lane; w < nwords; w += 64) s_best[w] = st_mask[w];
   }
   // while (mnIterations < mRansacMaxIts || nCurrentIterations < nIterations)
@@ -1329,19 +1337,19 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
   const int32_t* rs = tb.rand_stream + (size_t)f * pp.rand_per_frame;
   int accepted = 0, acc_iters = 0, acc_cnt = 0;
   float* scratch = tb.pnp_scratch + (size_t)f * cap * 5;
-  const int mset = pp.min_set;
-  const int chunk = mset == 4 ? PNP_CHUNK : 1;
+  const int mset = kGeneral ? pp.min_set : 4;
+  const int chunk = kGeneral ? 1 : PNP_CHUNK;
   __syncthreads();
 
   for (int c0 = start; c0 < total; c0 += chunk) {
     PROF(11);
     const int nact = min(chunk, total - c0);
-    if (mset == 4) {
+    if constexpr (!kGeneral) {
       const int it = c0 + hyp;
       const bool active = lane < 3 * PNP_CHUNK && hyp < nact;
       // minimal set: 4 draws without replacement from mvAllIndices via swap-with-back removal
       int modp[4], modv[4], nmod = 0, size = N;
-      double pws[12], us[8];
+      int draw[4];
       for (int k = 0; k < 4; k++) {
         const int ridx = 4 * it + k;
         const int r = (active && ridx < pp.rand_per_frame) ? rs[ridx] : 0;
@@ -1356,15 +1364,20 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
           if (modp[q] == randi) { modv[q] = backv; found = true; }
         if (!found) { modp[nmod] = randi; modv[nmod] = backv; nmod++; }
         size--;
-        const float* q = g_p + (size_t)val * 6;
-        pws[3 * k] = q[2];
-        pws[3 * k + 1] = q[3];
-        pws[3 * k + 2] = q[4];
-        us[2 * k] = q[0];
-        us[2 * k + 1] = q[1];
+        draw[k] = val;
       }
       double R[3][3], t[3];
-      const double err = epnp_minimal(active, variant, pws, us, cam, R, t, w_ut, w_L, LDS_PTR(s_Mrows), nact);
+      const double err = epnp_minimal(
+          active, variant,
+          [&](int k, double* pw, double* u) {
+            const float* q = g_p + (size_t)draw[k] * 6;
+            pw[0] = q[2];
+            pw[1] = q[3];
+            pw[2] = q[4];
+            u[0] = q[0];
+            u[1] = q[1];
+          },
+          cam, R, t, w_ut, w_L, LDS_PTR(s_Mrows), nact);
       // N = 1; if (e2 < e1) N = 2; if (e3 < e[N]) N = 3   (src/PnPsolver.cc:385-389)
       const double e1 = __shfl(err, hyp), e2 = __shfl(err, hyp + PNP_CHUNK), e3 = __shfl(err, hyp + 2 * PNP_CHUNK);
       int win = 1;
@@ -1438,7 +1451,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
       if (new_best) {
         best = cnt;
         for (int w = lane; w < nwords; w += 64) s_best[w] = s_mask[h][w];
-        for (int i = 0; i < 12; i++) bestT[i] = (float)s_Rt[h][i];
+        if (lane < 12) s_bestT[lane] = (float)s_Rt[h][lane];
       }
       // Refine() runs on every hypothesis that reaches minInliers (src/PnPsolver.cc:216) but is a pure function of the best
       // set: without a new best it repeats its last outcome -- a failure again (skipped), or, on a solver that has already
@@ -1498,7 +1511,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
     st[0] = accepted ? acc_iters : total;
     st[1] = best;
     st[2] = refine_ok;
-    for (int i = 0; i < 12; i++) st_T[i] = bestT[i];
+    for (int i = 0; i < 12; i++) st_T[i] = s_bestT[i];
   }
   if (accepted) {
     for (int i = lane; i < N; i += 64)
@@ -1512,7 +1525,7 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
       T_out[15] = 1.f;
       info[0] = 1; info[1] = acc_cnt; info[2] = 0; info[3] = acc_iters; info[7] = 1;
     }
-    continue;
+    return;
   }
   // ---- iterations exhausted (mnIterations >= mRansacMaxIts holds whenever the loop ends without a return)
   if (lane == 0) {
@@ -1524,8 +1537,8 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
       if ((s_best[i >> 6] >> (i & 63)) & 1ull) inl_out[g_idx[i]] = 1;
     if (lane == 0) {
       for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) T_out[r * 4 + c] = bestT[r * 3 + c];
-        T_out[r * 4 + 3] = bestT[9 + r];
+        for (int c = 0; c < 3; c++) T_out[r * 4 + c] = s_bestT[r * 3 + c];
+        T_out[r * 4 + 3] = s_bestT[9 + r];
       }
       T_out[12] = T_out[13] = T_out[14] = 0.f;
       T_out[15] = 1.f;
@@ -1533,11 +1546,10 @@ __global__ __launch_bounds__(64, 2) void k_pnp(const sd_keypoint* __restrict__ k
       info[1] = best;
     }
   }
-  }   // frames of this wave
 }
 
 // diagnostics: EPnP alone on explicit correspondences (one lane)
-__global__ void k_epnp_debug(int n, const double* pws, const double* us, EpnpCam cam, double* out13) {
+__global__ __launch_bounds__(64, 2) __attribute__((disable_tail_calls)) void k_epnp_debug(int n, const double* pws, const double* us, EpnpCam cam, double* out13) {
   __shared__ double s_work[PNP_CHUNK * (156 + 60)];
   __shared__ double s_mtm[144], s_terms[64 * 9], s_red[64], s_Rt[12];
   __shared__ double s_Mrows[PNP_CHUNK * 4 * 24];
@@ -1545,13 +1557,17 @@ __global__ void k_epnp_debug(int n, const double* pws, const double* us, EpnpCam
   const LArr ut{LDS_PTR(s_work)}, L{LDS_PTR(s_work) + 156 * PNP_CHUNK};
   double e;
   if (n == 4) {   // the RANSAC minimal-set solver: lanes 0, PNP_CHUNK, 2 * PNP_CHUNK run the three variants
-    double R[3][3], t[3], p[12], u[8];
-    for (int i = 0; i < 12; i++) p[i] = pws[i];
-    for (int i = 0; i < 8; i++) u[i] = us[i];
+    double R[3][3], t[3];
     const int hyp = lane % PNP_CHUNK, variant = lane / PNP_CHUNK + 1;
     const bool active = hyp == 0 && variant <= 3;
     const LArr h_ut{LDS_PTR(s_work) + hyp}, h_L{LDS_PTR(s_work) + 156 * PNP_CHUNK + hyp};   // per-hypothesis views, as in k_pnp
-    const double err = epnp_minimal(active, variant, p, u, cam, R, t, h_ut, h_L, LDS_PTR(s_Mrows), 1);
+    const double err = epnp_minimal(
+        active, variant,
+        [&](int k, double* pw, double* u) {
+          for (int j = 0; j < 3; j++) pw[j] = pws[3 * k + j];
+          for (int j = 0; j < 2; j++) u[j] = us[2 * k + j];
+        },
+        cam, R, t, h_ut, h_L, LDS_PTR(s_Mrows), 1);
     const double e1 = __shfl(err, 0), e2 = __shfl(err, PNP_CHUNK), e3 = __shfl(err, 2 * PNP_CHUNK);
     int win = 1;
     e = e1;
@@ -1563,7 +1579,8 @@ __global__ void k_epnp_debug(int n, const double* pws, const double* us, EpnpCam
     }
     __syncthreads();
   } else {
-    e = epnp_refit_wave(n, pws, us, cam, LDS_PTR(s_Rt), ut, L, LDS_PTR(s_terms), LDS_PTR(s_red), LDS_PTR(s_mtm));
+    epnp_refit_wave(n, pws, us, cam, LDS_PTR(s_Rt), ut, L, LDS_PTR(s_terms), LDS_PTR(s_red), LDS_PTR(s_mtm));
+    e = s_red[63];
   }
   if (lane == 0) {
     for (int i = 0; i < 12; i++) out13[i] = s_Rt[i];
@@ -1607,9 +1624,7 @@ int read_pnp_prof(unsigned long long* out32, int reset) {
 
 int launch_pnp(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sigma2, const PnpParams& pp,
                int n_frames, hipStream_t s) {
-  const int grid_cap = opt(OPT_PNP_GRID_CAP);   // option "track.pnp_grid_cap" (experiments): frames are walked by a capped grid
-  const int grid = grid_cap > 0 ? std::min(n_frames, grid_cap) : n_frames;
-  hipLaunchKernelGGL(k_pnp, dim3(grid), dim3(64), 0, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam, d_sigma2, pp,
+  hipLaunchKernelGGL(pp.min_set == 4 ? k_pnp<false> : k_pnp<true>, dim3(n_frames), dim3(64), 0, s, (cur->have_dist ? cur->d_kps_un : cur->d_kps), cur->d_nout, tb, cam, d_sigma2, pp,
                      n_frames);
   SD_HIP_CHECK(hipGetLastError());
   return SD_OK;
