@@ -53,12 +53,13 @@ W, H = 640, 480
 BOUNDS = (0.0, 640.0, 0.0, 480.0)
 PNP = dict(probability=0.99, min_inliers=10, max_iterations=200, min_set=4, epsilon=0.28, th2=5.991)
 RECORD_SOURCE = {"pnp": 0, "poseopt": 1, "motion_model": 2, "track": 3}
-# Vector-ALU issue model (measured with tools/valu_microbench.hip on an MI355X, profiles/r02_valu_microbench.json,
-# 8 waves per SIMD, every CU busy): a wave64 VOP2 instruction (v_add_u32, v_subrev) occupies a SIMD for 2.6 cycles, a VOP3
-# instruction with three sources -- v_max3_i32, v_min3_i32, v_perm_b32, v_alignbyte_b32, v_and_or_b32, v_mad_i32_i24, which is
-# what the FAST / pyramid / matcher kernels are made of -- for 4.2, v_pk_max_u16 / v_bcnt 4.3-4.5 (one wave alone: 5.4 for
-# all of them).  256 CUs x 4 SIMDs at CLK_GHZ.
-N_SIMD, CLK_GHZ, VALU_CYCLES_VOP2, VALU_CYCLES_VOP3 = 1024, 2.4, 2.6, 4.2
+# Vector-ALU issue model (measured with tools/valu_microbench.hip on an MI355X, profiles/r03_valu_microbench*.json,
+# 8 waves per SIMD, every CU busy, both timing methods within 1-10 %): a full-rate wave64 instruction (v_add / sub / and / or /
+# xor / lshrrev / mov, f32 add / mul / fma, 16-bit min / max / sub) occupies a SIMD for 2.2 shader cycles, a half-rate one -- 32-bit
+# min / max, v_max3 / v_min3, v_perm, v_alignbyte, shifts left, bfe, 24-bit multiplies, bcnt / mbcnt, dot4 / dot2, every v_pk_*, every
+# SDWA form, fp64, compares (4.26) -- for 4.15.  The names below say "vop2" / "vop3" for historical reasons: read them as the
+# full-rate and the half-rate bound.  256 CUs x 4 SIMDs at CLK_GHZ (2.38 GHz median under this load, tools/clock_probe.sh).
+N_SIMD, CLK_GHZ, VALU_CYCLES_VOP2, VALU_CYCLES_VOP3 = 1024, 2.4, 2.2, 4.15
 
 
 def _scene(args):

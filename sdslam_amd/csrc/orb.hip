@@ -1438,14 +1438,22 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   const bool src_aligned = (((uintptr_t)d_imgs | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) == 0;
   // FAST of level 0 reads the frames themselves when they are 4-byte aligned: it starts at once, beside the resize chain
   const bool fast0_direct = src_aligned && P.lv[0].ncells > 0 && opt(OPT_FAST0_FROM_FRAMES) != 0;
+  const int ring_slot = h->ev_calls % sd_orb::kRing;
+  int nfp = 0;   // FAST launches timed so far
+  auto fast_pair = [&](bool begin) {
+    if (prof && h->evf_ready && nfp < sd_orb::kFastPairs) (void)hipEventRecord(h->evf[ring_slot][2 * nfp + (begin ? 0 : 1)], h->fast_stream);
+    if (!begin) nfp++;
+  };
   if (fast0_direct) {
     if (prof) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
     fast_started = true;
     FastSrc fs0;
     memset(&fs0, 0, sizeof(fs0));
     fs0.pstride[0] = stride;
+    fast_pair(true);
     hipLaunchKernelGGL(k_fast_cells, dim3(P.lv[0].ncells, n), dim3(256), hp.fast_lds_level[0], h->fast_stream, h->d_cells, d_imgs,
                        frame_stride, fs0, 0, h->d_cand, P.cand_per_frame, h->d_cell_count, P.ncells, P.lv[0].cell0, P.thFAST);
+    fast_pair(false);
   }
   FastSrc fsrc;
   memset(&fsrc, 0, sizeof(fsrc));
@@ -1490,9 +1498,11 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
       SD_HIP_CHECK(hipStreamWaitEvent(h->fast_stream, h->ev_level[l], 0));
       if (prof && !fast_started) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
       fast_started = true;
+      fast_pair(true);
       hipLaunchKernelGGL(k_fast_cells, dim3(ncl, n), dim3(256), lds, h->fast_stream, h->d_cells, (const uint8_t*)h->d_pyr,
                          (size_t)P.pyr_frame_bytes, fsrc, SD_EDGE, h->d_cand, P.cand_per_frame, h->d_cell_count, P.ncells, P.lv[first].cell0,
                          P.thFAST);
+      fast_pair(false);
     }
   }
   if (prof) SD_HIP_CHECK(hipEventRecord(ev[1], ps));
@@ -1508,6 +1518,7 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   if (prof) {
     if (!fast_started) SD_HIP_CHECK(hipEventRecord(ev[8], h->fast_stream));
     SD_HIP_CHECK(hipEventRecord(ev[2], h->fast_stream));
+    h->evf_n[ring_slot] = h->evf_ready ? nfp : 0;
   }
   // ev_fast_done stands for "pyramid AND FAST complete" (a tracker's ImageAlign waits for it alone, track.hip wait_inputs): a
   // level without grid cells launches no FAST, so the FAST stream has not necessarily waited for that level's resize
@@ -1761,9 +1772,12 @@ void sd_orb_destroy(sd_orb* h) {
   for (int i = 0; i < 2; i++)
     if (h->ev_set_free[i]) (void)hipEventDestroy(h->ev_set_free[i]);
   if (h->ev_extract_done) (void)hipEventDestroy(h->ev_extract_done);
-  for (int r = 0; r < sd_orb::kRing; r++)
+  for (int r = 0; r < sd_orb::kRing; r++) {
     for (int i = 0; i < 10; i++)
       if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
+    for (int i = 0; i < 2 * sd_orb::kFastPairs; i++)
+      if (h->evf[r][i]) (void)hipEventDestroy(h->evf[r][i]);
+  }
   if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
   if (h->fast_stream) { (void)hipStreamSynchronize(h->fast_stream); (void)hipStreamDestroy(h->fast_stream); }
   for (int i = 0; i < SD_MAX_LEVELS; i++)
@@ -2050,6 +2064,12 @@ int sd_orb_sync(sd_orb* h) {
 
 int sd_orb_set_profiling(sd_orb* h, int on) {
   SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
+  if (on && !h->evf_ready) {
+    SD_HIP_CHECK(hipSetDevice(h->device));
+    for (int r = 0; r < sd_orb::kRing; r++)
+      for (int i = 0; i < 2 * sd_orb::kFastPairs; i++) SD_HIP_CHECK(hipEventCreate(&h->evf[r][i]));
+    h->evf_ready = true;
+  }
   h->profiling = on != 0;
   h->ev_calls = 0;
   return SD_OK;
@@ -2072,7 +2092,15 @@ int sd_orb_stage_ms(sd_orb* h, float* ms_out, int cap) {
     const int slot = (h->ev_calls - 1 - r) % sd_orb::kRing;
     for (int i = 0; i < ST_COUNT; i++) {
       float ms = 0;
-      SD_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[slot][kBegin[i]], h->ev[slot][kEnd[i]]));
+      if (i == ST_FAST && h->evf_n[slot] > 0) {   // sum of the k_fast_cells launches (what a kernel trace of the same run adds up to)
+        for (int k = 0; k < h->evf_n[slot]; k++) {
+          float one = 0;
+          SD_HIP_CHECK(hipEventElapsedTime(&one, h->evf[slot][2 * k], h->evf[slot][2 * k + 1]));
+          ms += one;
+        }
+      } else {
+        SD_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[slot][kBegin[i]], h->ev[slot][kEnd[i]]));
+      }
       ms_out[i] += ms / n;
     }
   }

@@ -87,6 +87,12 @@ struct sd_orb {
   // per call: [0] start, [1] pyramid end, [8]/[2] FAST start/end (fast stream), [9]/[7] select start/end, [3]/[6] blur start/end
   // (aux stream), [4]/[5] descriptor start/end
   hipEvent_t ev[kRing][10] = {};
+  // one (start, stop) pair per k_fast_cells launch: the FAST stage is reported as the SUM of its launches' durations (the stream
+  // waits for pyramid levels between them; ev[8] .. ev[2] would count those gaps).  Created when profiling is first switched on.
+  static const int kFastPairs = SD_MAX_LEVELS + 1;
+  hipEvent_t evf[kRing][2 * kFastPairs] = {};
+  int evf_n[kRing] = {};
+  bool evf_ready = false;
   int ev_calls = 0;   // calls recorded since profiling was (re-)enabled
 };
 
