@@ -32,7 +32,7 @@
 
 enum { OP_MAX3 = 0, OP_MIN3, OP_PERM, OP_MUL24, OP_MAD24, OP_CMP_SOR, OP_PKMAX16, OP_PKMIN16, OP_ADD, OP_BCNT, OP_ALIGNBYTE, OP_ANDOR, OP_LSHLADD,
        OP_CNDMASK, OP_SUBREV, OP_DS_READ_U8, OP_DS_READ_B32,
-       OP_DOT4, OP_DOT2, OP_SATPK, OP_MULLO, OP_CMP, OP_AND, OP_LSHL, OP_BFE, OP_FMA32, OP_FMA64, OP_ADD64, OP_MUL64, OP_RCP32, OP_CVT, OP_MAXI, OP_MAXU, OP_MAXF, OP_MINF, OP_MAX3F, OP_MED3F, OP_ADDF, OP_SUBF, OP_MULF, OP_OR, OP_XOR, OP_OR3, OP_ADD3, OP_LSHR, OP_MOV, OP_CMPF, OP_CMPU, OP_CMPE64, OP_SAD8, OP_CVTUB, OP_PKMAXI16, OP_PKADD16, OP_PKFMAF16, OP_PKMAXF16, OP_MAX3F16, OP_MBCNT, OP_SUBU, OP_MAXI16, OP_MINU16, OP_SUBU16, OP_MIN3U16, OP_MAX3U16, OP_CMPSDWA, OP_CMPU16, OP_LSHLADD1, OP_MINU16_SDWA, OP_MAXU16_SDWA, OP_SUBU16_SDWA, OP_MOV_DPP_WSHR, OP_MOV_DPP_ROWSHR, OP_DS_READ2_B32, OP_COUNT };
+       OP_DOT4, OP_DOT2, OP_SATPK, OP_MULLO, OP_CMP, OP_AND, OP_LSHL, OP_BFE, OP_FMA32, OP_FMA64, OP_ADD64, OP_MUL64, OP_RCP32, OP_CVT, OP_MAXI, OP_MAXU, OP_MAXF, OP_MINF, OP_MAX3F, OP_MED3F, OP_ADDF, OP_SUBF, OP_MULF, OP_OR, OP_XOR, OP_OR3, OP_ADD3, OP_LSHR, OP_MOV, OP_CMPF, OP_CMPU, OP_CMPE64, OP_SAD8, OP_CVTUB, OP_PKMAXI16, OP_PKADD16, OP_PKFMAF16, OP_PKMAXF16, OP_MAX3F16, OP_MBCNT, OP_SUBU, OP_MAXI16, OP_MINU16, OP_SUBU16, OP_MIN3U16, OP_MAX3U16, OP_CMPSDWA, OP_CMPU16, OP_LSHLADD1, OP_MINU16_SDWA, OP_MAXU16_SDWA, OP_SUBU16_SDWA, OP_MOV_DPP_WSHR, OP_MOV_DPP_ROWSHR, OP_DS_READ2_B32, OP_MULHI, OP_MULHI_U24, OP_MUL_U24, OP_MED3I, OP_COUNT };
 static const char* kNames[OP_COUNT] = {"v_max3_i32", "v_min3_i32", "v_perm_b32", "v_mul_i32_i24", "v_mad_i32_i24", "v_cmp_lt_i32+s_or_b64", "v_pk_max_u16",
                                        "v_pk_min_u16", "v_add_u32", "v_bcnt_u32_b32", "v_alignbyte_b32", "v_and_or_b32", "v_lshl_add_u32", "v_cndmask_b32",
                                        "v_subrev_u32", "ds_read_u8", "ds_read_b32",
@@ -40,7 +40,7 @@ static const char* kNames[OP_COUNT] = {"v_max3_i32", "v_min3_i32", "v_perm_b32",
                                        "v_bfe_u32", "v_fma_f32", "v_fma_f64", "v_add_f64", "v_mul_f64", "v_rcp_f32", "v_cvt_f32_u32",
                                        "v_max_i32", "v_max_u32", "v_max_f32", "v_min_f32", "v_max3_f32", "v_med3_f32", "v_add_f32", "v_sub_f32", "v_mul_f32", "v_or_b32", "v_xor_b32", "v_or3_b32", "v_add3_u32", "v_lshrrev_b32", "v_mov_b32", "v_cmp_lt_f32 (vcc)", "v_cmp_lt_u32 (vcc)", "v_cmp_lt_i32_e64 (sgpr pair)", "v_sad_u8", "v_cvt_f32_ubyte0", "v_pk_max_i16", "v_pk_add_u16", "v_pk_fma_f16", "v_pk_max_f16", "v_max3_f16", "v_mbcnt_lo_u32_b32", "v_sub_u32", "v_max_i16",
                                        "v_min_u16", "v_sub_u16", "v_min3_u16", "v_max3_u16", "v_cmp_lt_i32_sdwa (sgpr pair)", "v_cmp_gt_u16_e64 (sgpr pair)", "v_lshl_add_u32 (sgpr addend)",
-                                       "v_min_u16_sdwa (byte selects)", "v_max_u16_sdwa (byte selects)", "v_sub_u16_sdwa (byte select)", "v_mov_b32_dpp wave_shr:1", "v_mov_b32_dpp row_shr:1", "ds_read2_b32"};
+                                       "v_min_u16_sdwa (byte selects)", "v_max_u16_sdwa (byte selects)", "v_sub_u16_sdwa (byte select)", "v_mov_b32_dpp wave_shr:1", "v_mov_b32_dpp row_shr:1", "ds_read2_b32", "v_mul_hi_u32", "v_mul_hi_u32_u24", "v_mul_u32_u24", "v_med3_i32"};
 
 #define REP8(S)  S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 
@@ -344,6 +344,22 @@ __global__ __launch_bounds__(1024) void k_issue(unsigned long long* __restrict__
 #define S(i) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
         REP8(S)
 #undef S
+      } else if (OP == OP_MULHI) {
+#define S(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_MULHI_U24) {
+#define S(i) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_MUL_U24) {
+#define S(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        REP8(S)
+#undef S
+      } else if (OP == OP_MED3I) {
+#define S(i) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        REP8(S)
+#undef S
       } else if (OP == OP_DS_READ2_B32) {
         unsigned long long v[8];
 #define S(i) asm volatile("ds_read2_b32 %0, %1 offset1:33" : "=v"(v[i]) : "v"(a[i]));
@@ -485,7 +501,7 @@ int main(int argc, char** argv) {
            "of the waves of one SIMD, median over SIMDs; event = kernel time x measured clock / (instructions per wave x W); clock_GHz = delta s_memtime / "
            "delta s_memrealtime\",\n \"ops\": {\n");
     const int Ws[4] = {1, 2, 4, 8};
-    const int op_first = (argc > 1 && !strcmp(argv[1], "--new")) ? (int)OP_MAXI : ((argc > 1 && !strcmp(argv[1], "--new2")) ? (int)OP_MINU16 : ((argc > 1 && !strcmp(argv[1], "--new3")) ? (int)OP_MINU16_SDWA : 0));   // --new / --new2: only the round-3 additions
+    const int op_first = (argc > 1 && !strcmp(argv[1], "--new")) ? (int)OP_MAXI : ((argc > 1 && !strcmp(argv[1], "--new2")) ? (int)OP_MINU16 : ((argc > 1 && !strcmp(argv[1], "--new3")) ? (int)OP_MINU16_SDWA : ((argc > 1 && !strcmp(argv[1], "--new4")) ? (int)OP_MULHI : 0)));   // --new / --new2: only the round-3 additions
     for (int op = op_first; op < OP_COUNT; op++) {
       printf("  \"%s\": {", kNames[op]);
       for (int wi = 0; wi < 4; wi++) {
@@ -496,7 +512,7 @@ int main(int argc, char** argv) {
           C(OP_MAX3) C(OP_MIN3) C(OP_PERM) C(OP_MUL24) C(OP_MAD24) C(OP_CMP_SOR) C(OP_PKMAX16) C(OP_PKMIN16) C(OP_ADD) C(OP_BCNT) C(OP_ALIGNBYTE)
           C(OP_ANDOR) C(OP_LSHLADD) C(OP_CNDMASK) C(OP_SUBREV) C(OP_DS_READ_U8) C(OP_DS_READ_B32) C(OP_DOT4) C(OP_DOT2) C(OP_SATPK) C(OP_MULLO)
           C(OP_CMP) C(OP_AND) C(OP_LSHL) C(OP_BFE) C(OP_FMA32) C(OP_FMA64) C(OP_ADD64) C(OP_MUL64) C(OP_RCP32) C(OP_CVT)
-          C(OP_MAXI) C(OP_MAXU) C(OP_MAXF) C(OP_MINF) C(OP_MAX3F) C(OP_MED3F) C(OP_ADDF) C(OP_SUBF) C(OP_MULF) C(OP_OR) C(OP_XOR) C(OP_OR3) C(OP_ADD3) C(OP_LSHR) C(OP_MOV) C(OP_CMPF) C(OP_CMPU) C(OP_CMPE64) C(OP_SAD8) C(OP_CVTUB) C(OP_PKMAXI16) C(OP_PKADD16) C(OP_PKFMAF16) C(OP_PKMAXF16) C(OP_MAX3F16) C(OP_MBCNT) C(OP_SUBU) C(OP_MAXI16) C(OP_MINU16) C(OP_SUBU16) C(OP_MIN3U16) C(OP_MAX3U16) C(OP_CMPSDWA) C(OP_CMPU16) C(OP_LSHLADD1) C(OP_MINU16_SDWA) C(OP_MAXU16_SDWA) C(OP_SUBU16_SDWA) C(OP_MOV_DPP_WSHR) C(OP_MOV_DPP_ROWSHR) C(OP_DS_READ2_B32)
+          C(OP_MAXI) C(OP_MAXU) C(OP_MAXF) C(OP_MINF) C(OP_MAX3F) C(OP_MED3F) C(OP_ADDF) C(OP_SUBF) C(OP_MULF) C(OP_OR) C(OP_XOR) C(OP_OR3) C(OP_ADD3) C(OP_LSHR) C(OP_MOV) C(OP_CMPF) C(OP_CMPU) C(OP_CMPE64) C(OP_SAD8) C(OP_CVTUB) C(OP_PKMAXI16) C(OP_PKADD16) C(OP_PKFMAF16) C(OP_PKMAXF16) C(OP_MAX3F16) C(OP_MBCNT) C(OP_SUBU) C(OP_MAXI16) C(OP_MINU16) C(OP_SUBU16) C(OP_MIN3U16) C(OP_MAX3U16) C(OP_CMPSDWA) C(OP_CMPU16) C(OP_LSHLADD1) C(OP_MINU16_SDWA) C(OP_MAXU16_SDWA) C(OP_SUBU16_SDWA) C(OP_MOV_DPP_WSHR) C(OP_MOV_DPP_ROWSHR) C(OP_DS_READ2_B32) C(OP_MULHI) C(OP_MULHI_U24) C(OP_MUL_U24) C(OP_MED3I)
 #undef C
         }
         printf("\"W%d\": {\"simd_span\": %.3f, \"event\": %.3f, \"clock_GHz\": %.3f, \"waves_sharing_simd\": %.2f}%s", W, r.simd_span, r.event,
