@@ -743,6 +743,22 @@ def main():
         if args.hamming:
             m12, n12 = trk.get_point_matches(0, B)
             line["tracking"]["mean_point_matches"] = float(n12.mean())
+        if world == 1 and not args.no_extras:
+            # run-to-run spread (the headline is one timed region): three more blocks of the same step, each
+            # bracketed like the timed region, AFTER it; `value` stays the K-step figure above
+            blocks = []
+            nb = max(10, min(50, args.steps // 3))
+            for _ in range(3):
+                cur.sync()
+                trk.get_tracked(0, 1)
+                tb = time.perf_counter()
+                for k in range(nb):
+                    full_step(k)
+                cur.sync()
+                trk.get_tracked(0, 1)
+                blocks.append(B * nb / (time.perf_counter() - tb))
+            line["repeatability"] = {"blocks": 3, "steps_per_block": nb, "frames_per_s": blocks,
+                                     "spread": (max(blocks) - min(blocks)) / float(np.median(blocks))}
         if world == 1 and not args.orb_only and not args.hamming and not args.no_extras:
             line["stress"] = stress_legs(wl)
             line["h2d_inclusive"] = h2d_leg(wl)
