@@ -654,29 +654,42 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
     const int rpw = (nsr + 3) >> 2;
     const int y_lo = min(wave * rpw, nsr), y_hi = min(y_lo + rpw, nsr);
     int qn = 0;
-    for (int y = y_lo; y < y_hi; y++) {
-      const uint8_t* rowc = tile + __mul24(y + 3, TP) + 3 + sh;
-      for (int x0 = 0; x0 < zw; x0 += 64) {
-        // r3: straight-line code on 16-bit min / max.  The lanes beyond the zone read a clamped position and are masked out
-        // of the ballot on the scalar unit (a branch around the loads made the compiler rebuild the mask with v_cndmask +
-        // v_cmp); with D = max(min(p0, p8), min(p4, p12)) and Bt = min(max(p0, p8), max(p4, p12)) the compass condition
-        // ((k0 | k8) & (k4 | k12)) | ((b0 | b8) & (b4 | b12)), k = p < v - th, b = p > v + th, is max(v - D, Bt - v) > th:
-        // 9 full-rate 16-bit instructions and ONE compare instead of 6 half-rate min / max, two adds and two compares.
-        const int x = (int)fmin16((fu16)(x0 + lane), (fu16)(zw - 1));
-        const uint8_t* c = rowc + x;
+    // r3: the wave's band of rows is walked as ONE flat range of pixel indices i = y * zw + x, 64 at a time, instead of row by
+    // row: zones are 47...121 pixels wide, so row-wise chunks ran at 57-98 % lane use (74 % on average: a third more chunks, and
+    // this phase is bound by LDS-instruction issue as much as by the vector ALU).  Costs one multiply-high and one multiply-add per
+    // chunk (row = i / zw by magic number, LDS address = i + row * (TP - zw) + const); the queue entry IS i.
+    {
+      const int i_lo = __mul24(y_lo, zw), i_hi = __mul24(y_hi, zw);
+      const int pad = TP - zw;
+      const uint8_t* tile0 = tile + 3 * TP + 3 + sh;
+#ifdef FAST_SKIP_A
+      for (int i0 = i_hi; i0 < i_hi; i0 += 64) {
+#else
+      for (int i0 = i_lo; i0 < i_hi; i0 += 64) {
+#endif
+        // straight-line code on 16-bit min / max.  The lanes beyond the band read a clamped position and are masked out
+        // of the ballot on the scalar unit; with D = max(min(p0, p8), min(p4, p12)) and Bt = min(max(p0, p8), max(p4, p12))
+        // the compass condition ((k0 | k8) & (k4 | k12)) | ((b0 | b8) & (b4 | b12)), k = p < v - th, b = p > v + th, is
+        // max(v - D, Bt - v) > th: 9 full-rate 16-bit instructions and ONE compare.
+        const int i = min(i0 + lane, i_hi - 1);
+        const int y = (int)__umulhi((unsigned)i, magic);
+        const uint8_t* c = tile0 + (i + __mul24(y, pad));
         const fu16 v = c[0], p0 = c[3 * TP], p4 = c[3], p8 = c[-3 * TP], p12 = c[-3];
         const fu16 D = fmax16(fmin16(p0, p8), fmin16(p4, p12));
         const fu16 Bt = fmin16(fmax16(p0, p8), fmax16(p4, p12));
         const short da = (short)(v - D), db = (short)(Bt - v);
         bool pass = (da > db ? da : db) > (short)th;
-        if (zw - x0 < 64) pass = pass && (x0 + lane < zw);   // wave-uniform branch: only a row's last chunk pays this compare
+        if (i_hi - i0 < 64) pass = pass && (i0 + lane < i_hi);   // wave-uniform branch: only the band's last chunk pays this compare
         const unsigned long long m = __ballot(pass);
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (pass) *(uint16_t*)(smem + (qbase + 2u * (uint32_t)(qn + rank))) = (uint16_t)(__mul24(y, zw) + x);
+        if (pass) *(uint16_t*)(smem + (qbase + 2u * (uint32_t)(qn + rank))) = (uint16_t)i;
         qn += __popcll(m);
       }
     }
     FPROF(1);
+#ifdef FAST_SKIP_B   // instruction-budget experiments only (tools/fast_budget.sh): results are wrong by design
+    qn = 0;
+#endif
     // ---- B: ring test + score of the queued pixels in one pass (dense); corners re-compacted in place
     int cn = 0;
     for (int e0 = 0; e0 < qn; e0 += 64) {
@@ -695,6 +708,9 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
       cn += __popcll(m);
     }
     qn = cn;
+#ifdef FAST_SKIP_C
+    qn = 0;
+#endif
     FPROF(2);
     FPROF(3);
     __syncthreads();
