@@ -590,7 +590,8 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
   const int cell = (int)ucell + cell0;   // launched per level: the cells of a level are contiguous
   const CellGeom C = cells[cell];
   const int frame = (int)uframe;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: the band limits and loop counters derived from it stay scalar
   if (C.zw <= 0 || C.zh <= 0) {
     if (tid == 0) cell_count[(size_t)frame * ncells_total + cell] = 0;
     return;
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
         const short da = (short)(v - D), db = (short)(Bt - v);
         bool pass = (da > db ? da : db) > (short)th;
         if (i_hi - i0 < 64) pass = pass && (i0 + lane < i_hi);   // wave-uniform branch: only the band's last chunk pays this compare
-        const unsigned long long m = __ballot(pass);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         if (pass) *(uint16_t*)(smem + (qbase + 2u * (uint32_t)(qn + rank))) = (uint16_t)i;
         qn += __popcll(m);
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
         corner = sc_v >= th;
         if (corner && sc_v > 0) sc[__mul24(y + 1, SP) + x + 1] = (uint8_t)sc_v;
       }
-      const unsigned long long m = __ballot(corner);   // all reads of this chunk precede the writes (cn <= e0)
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(corner);   // all reads of this chunk precede the writes (cn <= e0)
       if (corner) queue[cn + __popcll(m & lt)] = (uint16_t)q;
       cn += __popcll(m);
     }
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
                    s > p[SP - 1] && s > p[SP] && s > p[SP + 1];
           }
         }
-        const unsigned long long m = __ballot(keep);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         cnt += __popcll(m);
         bits |= (unsigned long long)keep << j;
       }
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
       const int strip_total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
       for (int j = 0; j < nj; j++) {
         const bool keep = (bits >> j) & 1ull;
-        const unsigned long long m = __ballot(keep);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         if (keep) {
           const unsigned q = queue[j * 64 + lane];
           const int y = (int)__umulhi(q, magic), x = (int)q - __mul24(y, zw);
@@ -1243,7 +1244,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
       t1[q] = bbase[q][(uint32_t)(__mul24(r1, step[q]) + q1 + c19[q])];
     }
 #pragma unroll
-    for (int q = 0; q < DESC_KPW; q++) words[q][j] = __ballot(t0[q] < t1[q]);
+    for (int q = 0; q < DESC_KPW; q++) words[q][j] = __builtin_amdgcn_ballot_w64(t0[q] < t1[q]);
   }
 #pragma unroll
   for (int q = 0; q < DESC_KPW; q++) {

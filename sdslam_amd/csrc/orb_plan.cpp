@@ -89,7 +89,9 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
   {
     // option "extract.fast_merge_from" (A/B): first level of the merged FAST launch; >= nlevels = one launch per level.  Measured (1024 VGA
     // frames, 8 levels): full step 163.1 k frames/s with one launch per level, 167.0 k from level 4, 169.8 k from level 3,
-    // 165.6 k from level 2 (ORB alone is indifferent up to 3 and loses from 2 on: the merged launch waits for the whole pyramid)
+    // 165.6 k from level 2 (ORB alone is indifferent up to 3 and loses from 2 on: the merged launch waits for the whole pyramid).
+    // r3, after k_fast_cells itself got 12 % shorter (flat phase A, scalar loop control): from level 5 203.3 k, 6: 202.7 k,
+    // 4: 197.7-203.9 k (two states), 3: 194.7 k, none: 201.5 k (alternating runs) -- the default moved from 3 to 5
     hp.fast_merge_from = std::max(1, opt(OPT_FAST_MERGE_FROM));
   }
   for (int l = 0; l < SD_MAX_LEVELS; l++) hp.fast_lds_level[l] = 0;

@@ -119,6 +119,25 @@ def test_selection_paths(sd, oracle, opts):
         ext.close()
 
 
+@pytest.mark.parametrize("opts", [{"extract.fast_merge_from": 3}, {"extract.fast_merge_from": 8}, {"extract.fast_merge_from": 1},
+                                  {"extract.fast_lds_kb": 12, "extract.fast_lds_whole_kb": 12}, {"extract.fast0_from_frames": 0}],
+                         ids=["merge3", "merge_none", "merge_all", "small_strips", "fast0_from_pyramid"])
+def test_fast_plan_options(sd, oracle, opts):
+    """The FAST launch plan never changes results: which levels share a launch (default: 5...), the LDS budgets that decide
+    whole-cell vs strip processing (12 KB forces several strips per cell on every level), level 0 from the padded pyramid."""
+    with sd.options(opts):
+        ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2)
+        ora = oracle.OrbOracle(1000, 1.2, 8, 20)
+        rng = np.random.default_rng(7)
+        imgs = np.stack([make_image(71), rng.integers(0, 256, size=(480, 640)).astype(np.uint8)])
+        kps, desc, n = ext.extract_batch(imgs)
+        for b in range(2):
+            ok, od = ora.extract(imgs[b])
+            assert len(ok) > 500 and n[b] == len(ok), (opts, b)
+            assert np.array_equal(kps[b, :n[b]], ok) and np.array_equal(desc[b, :n[b]], od), (opts, b)
+        ext.close()
+
+
 @pytest.mark.parametrize("shape,cfg", [((479, 637), (1000, 1.2, 8, 20)), ((242, 321), (500, 1.2, 6, 20)),
                                        ((480, 640), (1000, 2.0, 4, 20)), ((360, 486), (800, 1.5, 5, 12))])
 def test_odd_geometries_all_stages(sd, oracle, shape, cfg):

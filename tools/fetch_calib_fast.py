@@ -26,8 +26,10 @@ d = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 CFG, W, H = (1000, 1.2, 8, 20), 640, 480
 info = sdslam_amd.plan_info(*CFG, W, H)
-merge_from = 3
-launches = {"level0 (frames, direct)": [0], "level1": [1], "level2": [2], "levels3-7 (merged)": list(range(merge_from, CFG[2]))}
+merge_from = sdslam_amd.get_option("extract.fast_merge_from")
+launches = {("level0 (frames, direct)" if l == 0 else f"level{l}"): [l] for l in range(min(merge_from, CFG[2]))}
+if merge_from < CFG[2]:
+    launches[f"levels{merge_from}-{CFG[2] - 1} (merged)"] = list(range(merge_from, CFG[2]))
 uniq, grid = {}, {}
 for name, levels in launches.items():
     total, ncells = 0, 0
@@ -50,7 +52,7 @@ for name, levels in launches.items():
         ncells += int(((info["cells"][:, 0] == l) & (info["cells"][:, 3] <= 0)).sum())
     uniq[name] = total
     grid[name] = ncells
-# the four launches of a step come in a fixed order (level 0 straight from the frames, level 1, level 2, the merged small
+# the launches of a step come in a fixed order (level 0 straight from the frames, level 1, level 2, the merged small
 # levels: orb.hip pipeline_body); levels 0 and 1 have the same grid size, so position in dispatch order tells them apart
 disp = []
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -61,7 +63,7 @@ disp.sort()
 rows = defaultdict(list)
 names = list(launches)
 for k, (_, g, v) in enumerate(disp):
-    name = names[k % 4]
+    name = names[k % len(names)]
     if g == grid[name] * 256 * B:      # Grid_Size is in work-items: cells x 256 threads x frames
         rows[name].append(v)
 out = {}
