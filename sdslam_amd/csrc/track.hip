@@ -146,6 +146,7 @@ int sd_track_create(sd_orb* cur, sd_orb* ref, int max_points, int max_batch, int
   A(dalloc(h, &tb.mt_pt, B * M));
   A(dalloc(h, &tb.mt_key, B * 2048));
   A(dalloc(h, &tb.mt_cstart, B * (64 * 48 + 4)));
+  A(dalloc(h, &tb.retry_list, B + 1));
   A(dalloc(h, &tb.uright, B * K));
   A(dalloc(h, &tb.depth, B * K));
   A(dalloc(h, &tb.rand_stream, B * (size_t)h->rand_per_frame));
@@ -579,7 +580,7 @@ int sd_track_with_motion_model(sd_track* h, int n_frames, int align_mode, float 
     if (rc != SD_OK) return rc;
   }
   if (h->profiling) SD_HIP_CHECK(hipEventRecord(ev1[2], s));
-  rc = launch_match(h->cur, tb, h->cam, h->d_sf, n_frames, th, mono, 1, s);
+  rc = launch_match(h->cur, tb, h->cam, h->d_sf, n_frames, th, mono, 1, s, 0, min_matches);   // (lists the frames that need the retry)
   if (rc == SD_OK) rc = launch_match(h->cur, tb, h->cam, h->d_sf, n_frames, 2.f * th, mono, 1, s, min_matches);
   if (h->profiling) { SD_HIP_CHECK(hipEventRecord(ev1[3], s)); h->ev_calls[1]++; }
   if (rc != SD_OK) return rc;

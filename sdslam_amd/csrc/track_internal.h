@@ -37,6 +37,7 @@ struct TrackBuffers {
   uint32_t* mt_pt;       // [B][M]    ... offset << 16 | count of every point's keys
   uint32_t* mt_key;      // [B][2048] ... the frame's sorted grid keys and cell starts (slow path of the assignment loop)
   uint16_t* mt_cstart;   // [B][64*48+4]
+  int32_t* retry_list;   // [1 + B]: count, then the frames whose first search found too few matches (TrackWithMotionModel's retry)
   float* uright;         // [B][kp_cap]  CurrentFrame.mvuRight (-1: no stereo/depth information)
   float* depth;          // [B][kp_cap]  CurrentFrame.mvDepth
   // PnP
@@ -106,7 +107,7 @@ int launch_align(const sd_orb* cur, const sd_orb* ref, const TrackBuffers& tb, c
                  const float* d_sf, int n_frames, int mode, hipStream_t s);
 // retry_below > 0: only frames whose last search found fewer matches run, from the PRIOR pose (which becomes the frame's pose)
 int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, int n_frames, float th,
-                 int mono, int check_ori, hipStream_t s, int retry_below = 0);
+                 int mono, int check_ori, hipStream_t s, int retry_below = 0, int note_below = 0);
 // min_matches > 0: the tail of Tracking::TrackWithMotionModel around PoseOptimization (gate, outlier discard, tw_info)
 // source 2 (+ min_inliers): TrackLocalMap -- the union of both match vectors, mnMatchesInliers, tl_info
 int launch_pose_opt(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_inv_sigma2, int source, int n_frames,

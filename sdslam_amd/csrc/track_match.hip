@@ -494,12 +494,10 @@ __device__ __forceinline__ void match_geom(MatchGeom& G, const double* Tc, const
   }
 }
 
-__global__ __launch_bounds__(64 * MT_WAVES) void k_match_cand(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
-                                                               const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
-                                                               const float* __restrict__ sf, float th, int mono, int KP2, int retry_below) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = 64 * MT_WAVES;
-  if (retry_below > 0 && tb.n_matches[f] >= retry_below) return;   // (k_match_assign applies the same gate)
+__device__ __forceinline__ void match_cand_frame(const int f, uint8_t* smem, const sd_keypoint* __restrict__ kps_all,
+                                                 const uint8_t* __restrict__ desc_all, const int32_t* __restrict__ nkp_all, const TrackBuffers& tb,
+                                                 const TrackCam& cam, const float* __restrict__ sf, float th, int mono, int KP2, int retry_below) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = 64 * MT_WAVES;
   const int MP = tb.max_points;
   uint32_t* s_key = (uint32_t*)smem;
   uint32_t* s_off = s_key + KP2;                                  // exclusive prefix of the counts (may exceed the list)
@@ -604,13 +602,29 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_cand(const sd_keypoint*
   }
 }
 
-__global__ __launch_bounds__(64) void k_match_assign(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
-                                                     const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
-                                                     const float* __restrict__ sf, float th, int mono, int check_ori, int KP2,
-                                                     int retry_below) {
+// r3: the retry pass of TrackWithMotionModel (src/Tracking.cc:681-686: search again from the predicted pose with 2 th when fewer
+// than 20 matches were found) walks a LIST of the frames that need it -- written by the first pass's assignment kernel -- with a
+// small grid of ONE-WAVE workgroups.  It used to be a second full-grid launch of both kernels whose workgroups looked at their
+// frame's count and left: eight-wave, 14-KB workgroups still have to be PLACED on a machine the extraction kernels fill -- 0.7-1.0 ms
+// of the tracking chain per step in which nothing was computed (k_match_cand 2 x 1.10 ms in the pipeline against 0.33 + 0.002 alone;
+// 128 such workgroups instead of 1024 took as long).
+#define MT_RETRY_GRID 128
+__global__ __launch_bounds__(64 * MT_WAVES) void k_match_cand(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
+                                                               const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
+                                                               const float* __restrict__ sf, float th, int mono, int KP2, int note_below) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int f = blockIdx.x, lane = threadIdx.x;
-  if (retry_below > 0 && tb.n_matches[f] >= retry_below) return;
+  if (note_below > 0 && blockIdx.x == 0 && threadIdx.x == 0) tb.retry_list[0] = 0;   // the assignment kernel behind this launch fills it
+  match_cand_frame(blockIdx.x, smem, kps_all, desc_all, nkp_all, tb, cam, sf, th, mono, KP2, 0);
+}
+// RETRY: TrackWithMotionModel's second search of a frame (from the predicted pose, with the doubled window) done by THIS wave alone:
+// every valid point goes through the per-point path that walks its window on the grid copy the first pass left in HBM (the keypoints,
+// hence the grid, are the same); no candidate kernel runs for a retry.
+template <bool RETRY>
+__device__ __forceinline__ void match_assign_frame(const int f, uint8_t* smem, const sd_keypoint* __restrict__ kps_all,
+                                                   const uint8_t* __restrict__ desc_all, const int32_t* __restrict__ nkp_all,
+                                                   const TrackBuffers& tb, const TrackCam& cam, const float* __restrict__ sf, float th, int mono,
+                                                   int check_ori, int KP2, int retry_below, int note_below) {
+  const int lane = threadIdx.x;
   const int MP = tb.max_points, cap = tb.kp_cap;
   uint32_t* s_ev = (uint32_t*)smem;                      // one entry per ASSIGNMENT (rotHist[bin].push_back): <= n_last
   uint32_t* s_obs = s_ev + MP;
@@ -625,8 +639,21 @@ __global__ __launch_bounds__(64) void k_match_assign(const sd_keypoint* __restri
   const uint32_t* g_pt = tb.mt_pt + (size_t)f * MP;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   // the first three chunks of the list and the first group of per-point words are on their way while LDS is initialised
-  uint32_t c0 = g_list[lane], c1 = g_list[64 + lane], c2 = g_list[128 + lane];
-  uint32_t pcv_next = lane < n_last ? g_pt[lane] : 0u;
+  uint32_t c0 = 0, c1 = 0, c2 = 0;
+  if (!RETRY) { c0 = g_list[lane]; c1 = g_list[64 + lane]; c2 = g_list[128 + lane]; }
+  const uint8_t* l_valid = tb.valid + (size_t)f * MP;
+  auto point_word = [&](int m) -> uint32_t {   // first pass: what the candidate kernel left for point m; retry: "evaluate it here"
+    if (m >= n_last) return 0u;
+    return RETRY ? (l_valid[m] != 0 ? 0xFFFFFFFFu : 0u) : g_pt[m];
+  };
+  uint32_t pcv_next = point_word(lane);
+  MatchGeom Gr;
+  if (RETRY) {   // the retry searches from the predicted pose, which becomes the frame's pose (SetPose(predicted_pose), src/Tracking.cc:683)
+    const double* Tp = tb.Tprior + (size_t)f * 16;
+    match_geom(Gr, Tp, tb.Tref + (size_t)f * 16, cam, th, mono);
+    if (lane < 16) tb.Tcur[(size_t)f * 16 + lane] = Tp[lane];
+    if (lane == 0) tb.tw_info[(size_t)f * 4 + 3] = 1;
+  }
   for (int i = lane; i < KP2; i += 64) s_match[i] = -1;   // CurrentFrame.mvpMapPoints filled with NULL (src/Tracking.cc:676)
   for (int m0 = 0; m0 < ((MP + 63) & ~63); m0 += 64) {
     const int m = m0 + lane;
@@ -642,7 +669,7 @@ __global__ __launch_bounds__(64) void k_match_assign(const sd_keypoint* __restri
   int nmatches = 0, nev = 0, cbase = 0;
   for (int base = 0; base < n_last; base += 64) {
     const uint32_t pcv = pcv_next;
-    pcv_next = (base + 64 + lane < n_last) ? g_pt[base + 64 + lane] : 0u;
+    pcv_next = point_word(base + 64 + lane);
     unsigned long long todo = __ballot(pcv != 0);
     while (todo) {
       const int jsel = __ffsll((long long)todo) - 1;
@@ -651,7 +678,7 @@ __global__ __launch_bounds__(64) void k_match_assign(const sd_keypoint* __restri
       const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)pcv, jsel);
       const uint32_t obs_i = (s_obs[i >> 5] >> (i & 31)) & 1u;   // independent of the assignments: issued ahead of the chain
       uint32_t best = 0x7FFFFFFFu;
-      if (pc != 0xFFFFFFFFu) {
+      if (!RETRY && pc != 0xFFFFFFFFu) {
         int off = pc >> 16, cnt = pc & 0xffff;
         while (cnt > 0) {
           while (off >= cbase + 64) {   // next chunk of the stream (offsets only grow: the list is in point order)
@@ -670,7 +697,8 @@ __global__ __launch_bounds__(64) void k_match_assign(const sd_keypoint* __restri
         }
       } else {   // keys not in the list: walk the window now, against the assignments so far (k_match's slow path)
         MatchGeom G;
-        match_geom(G, tb.Tcur + (size_t)f * 16, tb.Tref + (size_t)f * 16, cam, th, mono);   // (a retry: k_match_cand has set Tcur = Tprior)
+        if (RETRY) G = Gr;
+        else match_geom(G, tb.Tcur + (size_t)f * 16, tb.Tref + (size_t)f * 16, cam, th, mono);
         const MatchLds SG = {tb.mt_key + (size_t)f * MT_MAXKP, tb.mt_cstart + (size_t)f * MT_HBM_CSTART, s_match, s_obs, nullptr};
         int seq = 0;
         best = match_point<2>(i, kps, desc_all + (size_t)fc * cap * 32, tb.Xw + (size_t)f * MP * 3, tb.mp_desc + (size_t)f * MP * 32,
@@ -741,7 +769,29 @@ __global__ __launch_bounds__(64) void k_match_assign(const sd_keypoint* __restri
     const int m = i < KP2 ? (int)s_match[i] : -1;
     out[i] = m < 0 ? -1 : (m & 2047);
   }
-  if (lane == 0) tb.n_matches[f] = nmatches;
+  if (lane == 0) {
+    tb.n_matches[f] = nmatches;
+    if (retry_below == 0 && note_below > 0 && nmatches < note_below)   // this frame goes through the retry pass (any order: frames are independent)
+      tb.retry_list[1 + atomicAdd(&tb.retry_list[0], 1)] = f;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_match_assign(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
+                                                     const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
+                                                     const float* __restrict__ sf, float th, int mono, int check_ori, int KP2, int note_below) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  match_assign_frame<false>(blockIdx.x, smem, kps_all, desc_all, nkp_all, tb, cam, sf, th, mono, check_ori, KP2, 0, note_below);
+}
+__global__ __launch_bounds__(64) void k_match_assign_retry(const sd_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
+                                                           const int32_t* __restrict__ nkp_all, TrackBuffers tb, TrackCam cam,
+                                                           const float* __restrict__ sf, float th, int mono, int check_ori, int KP2,
+                                                           int retry_below) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int cnt = tb.retry_list[0];
+  for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
+    match_assign_frame<true>(tb.retry_list[1 + it], smem, kps_all, desc_all, nkp_all, tb, cam, sf, th, mono, check_ori, KP2, retry_below, 0);
+    __syncthreads();   // (one wave: orders the LDS reuse)
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1092,7 +1142,7 @@ int launch_match_local(const sd_orb* cur, const TrackBuffers& tb, const TrackCam
 }
 
 int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam, const float* d_sf, int n_frames, float th,
-                 int mono, int check_ori, hipStream_t s, int retry_below) {
+                 int mono, int check_ori, hipStream_t s, int retry_below, int note_below) {
   int KP2 = 64;
   while (KP2 < tb.kp_cap) KP2 <<= 1;
   SD_REQUIRE(KP2 <= MT_MAXKP && tb.max_points <= 2048, SD_ERR_CAPACITY, "matcher supports at most 2048 keypoints / map points per frame");
@@ -1104,10 +1154,17 @@ int launch_match(const sd_orb* cur, const TrackBuffers& tb, const TrackCam& cam,
     const size_t lds_c = (size_t)KP2 * 4 + (size_t)MP * 4 + (size_t)(MP + (MP & 1)) * 2 + (size_t)((MP + 31) >> 5) * 4 +
                          (GRID_COLS * GRID_ROWS + 2) * 2 + 8;
     const size_t lds_a = (size_t)MP * 4 + (size_t)((MP + 31) >> 5) * 4 + (HISTO_LENGTH + 2) * 4 + (size_t)KP2 * 2;
-    hipLaunchKernelGGL(k_match_cand, dim3(n_frames), dim3(64 * MT_WAVES), lds_c, s, kps, cur->d_desc, cur->d_nout, tb, cam, d_sf, th, mono, KP2,
-                       retry_below);
-    hipLaunchKernelGGL(k_match_assign, dim3(n_frames), dim3(64), lds_a, s, kps, cur->d_desc, cur->d_nout, tb, cam, d_sf, th, mono, check_ori,
-                       KP2, retry_below);
+    // first pass: one workgroup per frame (note_below > 0: frames with fewer matches are listed for a retry pass);
+    // retry pass (retry_below > 0): a small grid walks that list
+    if (retry_below > 0) {   // one wave per listed frame does the whole second search (match_assign_frame<true>)
+      hipLaunchKernelGGL(k_match_assign_retry, dim3(std::min(n_frames, MT_RETRY_GRID)), dim3(64), lds_a, s, kps, cur->d_desc, cur->d_nout, tb, cam,
+                         d_sf, th, mono, check_ori, KP2, retry_below);
+    } else {
+      hipLaunchKernelGGL(k_match_cand, dim3(n_frames), dim3(64 * MT_WAVES), lds_c, s, kps, cur->d_desc, cur->d_nout, tb, cam, d_sf, th, mono, KP2,
+                         note_below);
+      hipLaunchKernelGGL(k_match_assign, dim3(n_frames), dim3(64), lds_a, s, kps, cur->d_desc, cur->d_nout, tb, cam, d_sf, th, mono, check_ori,
+                         KP2, note_below);
+    }
   } else {
     hipLaunchKernelGGL(k_match, dim3(n_frames), dim3(64 * MT_WAVES), lds, s, kps, cur->d_desc, cur->d_nout, tb, cam, d_sf, th, mono, check_ori,
                        KP2, retry_below);
