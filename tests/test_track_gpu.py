@@ -550,6 +550,48 @@ def test_track_with_motion_model_decisions(sd, oracle, rig, match_mode):
     assert {(2, 0), (2, 1), (0, 1)} <= seen and any(s == 1 for s, _ in seen), seen
 
 
+def test_motion_model_retry_list_longer_than_its_grid(sd, oracle, rig):
+    """TrackWithMotionModel's retry pass walks a device-built list of frames with a grid of 128 one-wave workgroups: 320 slots
+    (the rig's four frame pairs, 80 times) with priors that send at least half of them through the retry make every workgroup
+    take several list entries; every slot equals the oracle's result for its scene (match vector, decisions, pose)."""
+    CFG, NL = rig["cfg"], rig["NL"]
+    scenes, oras = rig["scenes"], rig["oras"]
+    REP, B = 80, 320
+    cur = sd.ORBextractor(*CFG, 640, 480, B)
+    ref = sd.ORBextractor(*CFG, 640, 480, B)
+    trk = None
+    try:
+        cur.extract_batch(np.stack([scenes[i % 4]["cur"] for i in range(B)]))
+        ref.extract_batch(np.stack([scenes[i % 4]["ref"] for i in range(B)]))
+        trk = sd.Tracker(cur, ref, max_points=1000, max_batch=B, pnp_max_iterations=300)
+        trk.set_camera(*K, 0.0, BOUNDS)
+        trk.set_last(0, [oras[i % 4]["last"] for i in range(B)])
+        th = 0.6
+        pert = [(0.5, 0.5), (1.5, 1.5), (3.0, 3.0), (2.5, 2.5)]
+        T0 = [synth.se3_exp((0.004 * a, -0.003 * a, 0.002 * a), (0.05 * b, 0.03 * b, -0.04 * b)) @ s["T_cur"] for (a, b), s in zip(pert, scenes)]
+        trk.set_poses(0, [scenes[i % 4]["T_ref"] for i in range(B)], [T0[i % 4] for i in range(B)])
+        trk.track_with_motion_model(B, th=th, mono=True, align_mode=-1)
+        tw, gp, (cm, nm) = trk.get_tracked(0, B), trk.get_pose_opt(0, B), trk.get_matches(0, B)
+        exp = []
+        for i in range(4):
+            o = oras[i]
+            pc = [o["oc"].level(l) for l in range(NL)]
+            pr = [o["orf"].level(l) for l in range(NL)]
+            exp.append(oracle.track_with_motion_model(pc, pr, o["tab"], o["ck"], o["cd"], BOUNDS, K, scenes[i]["T_ref"], T0[i], o["last"], th,
+                                                      mono=True, align_mode=-1))
+        assert sum(int(r["retried"]) for r in exp) * REP > 128, [r["retried"] for r in exp]   # more list entries than workgroups
+        for b in range(B):
+            r, n = exp[b % 4], len(oras[b % 4]["ck"])
+            assert tw["status"][b] == r["status"] and tw["retried"][b] == r["retried"] and tw["nmatches"][b] == r["nmatches"], b
+            assert np.array_equal(cm[b, :n], r["match"]) and (cm[b, n:] == -1).all(), b
+            assert np.abs(gp["T"][b] - r["T"]).max() <= POSE_TOL, b
+    finally:
+        if trk is not None:
+            trk.close()
+        cur.close()
+        ref.close()
+
+
 def test_track_local_map_after_motion_model(sd, oracle, rig):
     """Tracking::TrackLocalMap (src/Tracking.cc:720-751) chained behind TrackWithMotionModel without a host round trip:
     the local search is closed where the frame match has observations, PoseOptimization runs over the union of both
