@@ -35,7 +35,7 @@ const char* sd_version(void);
  *   extract.use_graph          0     1: replay the extraction pipeline as a captured hipGraph (slower on ROCm 7.2; kept for tests)
  *   extract.select_small_cap   0     >0: cap (entries) of the per-cell selection buffer -- tests force the large-cell paths
  *   extract.select_big_cap     0     >0: cap of the per-level selection buffer -- tests force the serial fallback
- *   extract.fast_merge_from    5     plan: first pyramid level of the merged FAST launch (>= nlevels: one launch per level)
+ *   extract.fast_merge_from    6     plan: first pyramid level of the merged FAST launch (>= nlevels: one launch per level)
  *   extract.fast_lds_kb        24    plan: LDS budget of a FAST strip
  *   extract.fast_lds_whole_kb  40    plan: LDS budget under which a cell of the unmerged levels is processed as one strip
  *   track.stream_priority      2     create: priority of the tracking stream, 0 lowest / 1 normal / 2 highest

@@ -728,12 +728,14 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(const CellGeom* __restric
           const unsigned q = queue[e];
           const int y = (int)__umulhi(q, magic), x = (int)q - __mul24(y, zw);
           const int yz = sr0 + y;
-          if (yz >= r0 && yz < r1) {
-            const uint8_t* p = sc + __mul24(y + 1, SP) + x + 1;
-            const int s = p[0];
-            keep = s > 0 && s > p[-1] && s > p[1] && s > p[-SP - 1] && s > p[-SP] && s > p[-SP + 1] &&
-                   s > p[SP - 1] && s > p[SP] && s > p[SP + 1];
-          }
+          // r3: the nine scores are read FIRST and reduced with max3 (strictly greater than all eight neighbours = greater than their
+          // maximum).  Written as a short-circuit && chain this was nine dependent LDS round trips per chunk, each behind a branch
+          // (ds_read_u8 -> s_waitcnt -> v_cmp -> s_and_saveexec); rows of the halo are inside the score map too, so nothing is conditional.
+          const uint8_t* p = sc + __mul24(y + 1, SP) + x + 1;
+          const int s = p[0];
+          const int n0 = p[-1], n1 = p[1], n2 = p[-SP - 1], n3 = p[-SP], n4 = p[-SP + 1], n5 = p[SP - 1], n6 = p[SP], n7 = p[SP + 1];
+          const int nm = max(max(max(n0, n1), n2), max(max(max(n3, n4), n5), max(n6, n7)));
+          keep = (s > 0) & (s > nm) & (yz >= r0) & (yz < r1);
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         cnt += __popcll(m);

@@ -91,7 +91,9 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
     // frames, 8 levels): full step 163.1 k frames/s with one launch per level, 167.0 k from level 4, 169.8 k from level 3,
     // 165.6 k from level 2 (ORB alone is indifferent up to 3 and loses from 2 on: the merged launch waits for the whole pyramid).
     // r3, after k_fast_cells itself got 12 % shorter (flat phase A, scalar loop control): from level 5 203.3 k, 6: 202.7 k,
-    // 4: 197.7-203.9 k (two states), 3: 194.7 k, none: 201.5 k (alternating runs) -- the default moved from 3 to 5
+    // 4: 197.7-203.9 k (two states), 3: 194.7 k, none: 201.5 k (alternating runs) -- the default moved from 3 to 5; and, after the
+    // NMS phase lost its nine dependent LDS round trips (alone another 6 % shorter), to 6: full step 205.4 k vs 205.0 k, TrackWithMotionModel
+    // 208.4 k vs 206.6 k, ORB-only 262.4 k vs 260.1 k, 1280x720 93.0 k vs 89.0 k
     hp.fast_merge_from = std::max(1, opt(OPT_FAST_MERGE_FROM));
   }
   for (int l = 0; l < SD_MAX_LEVELS; l++) hp.fast_lds_level[l] = 0;

@@ -19,7 +19,7 @@ static const OptDef kOpts[OPT_COUNT] = {
     {"extract.use_graph", 0, 0, 1},
     {"extract.select_small_cap", 0, 0, 1 << 20},
     {"extract.select_big_cap", 0, 0, 1 << 20},
-    {"extract.fast_merge_from", 5, 1, 64},
+    {"extract.fast_merge_from", 6, 1, 64},
     {"extract.fast_lds_kb", 24, 4, 160},
     {"extract.fast_lds_whole_kb", 40, 4, 160},
     {"track.stream_priority", 2, 0, 2},

@@ -119,11 +119,11 @@ def test_selection_paths(sd, oracle, opts):
         ext.close()
 
 
-@pytest.mark.parametrize("opts", [{"extract.fast_merge_from": 3}, {"extract.fast_merge_from": 8}, {"extract.fast_merge_from": 1},
+@pytest.mark.parametrize("opts", [{"extract.fast_merge_from": 3}, {"extract.fast_merge_from": 5}, {"extract.fast_merge_from": 8}, {"extract.fast_merge_from": 1},
                                   {"extract.fast_lds_kb": 12, "extract.fast_lds_whole_kb": 12}, {"extract.fast0_from_frames": 0}],
-                         ids=["merge3", "merge_none", "merge_all", "small_strips", "fast0_from_pyramid"])
+                         ids=["merge3", "merge5", "merge_none", "merge_all", "small_strips", "fast0_from_pyramid"])
 def test_fast_plan_options(sd, oracle, opts):
-    """The FAST launch plan never changes results: which levels share a launch (default: 5...), the LDS budgets that decide
+    """The FAST launch plan never changes results: which levels share a launch (default: 6...), the LDS budgets that decide
     whole-cell vs strip processing (12 KB forces several strips per cell on every level), level 0 from the padded pyramid."""
     with sd.options(opts):
         ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 2)
