@@ -1428,18 +1428,30 @@ __global__ __launch_bounds__(64, 2) __attribute__((disable_tail_calls)) void k_p
     }
     __syncthreads();
     PROF(12);
-    // inlier masks of the chunk's hypotheses
-    for (int h = 0; h < nact; h++) {
-      int cnt = 0;
+    // inlier masks of the chunk's hypotheses.  r3: a correspondence is fetched ONCE and tested against every hypothesis of the chunk
+    // (was: hypothesis-major, 8 x 4 rounds of six global loads each, every one waited for)
+    {
+      int cnts[PNP_CHUNK];
+#pragma unroll
+      for (int h = 0; h < PNP_CHUNK; h++) cnts[h] = 0;
       for (int w = 0; w < nwords; w++) {
         const int i = w * 64 + lane;
-        bool in = false;
-        if (i < N) in = pnp_is_inlier(s_Rt[h], g_p + (size_t)i * 6, cam);
-        const unsigned long long bal = __ballot(in);
-        if (lane == 0) s_mask[h][w] = bal;
-        cnt += __popcll(bal);
+        float q[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) q[k] = i < N ? g_p[(size_t)i * 6 + k] : 0.f;
+#pragma unroll
+        for (int h = 0; h < PNP_CHUNK; h++) {
+          if (h < nact) {
+            const bool in = i < N && pnp_is_inlier(s_Rt[h], q, cam);
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
+            if (lane == 0) s_mask[h][w] = bal;
+            cnts[h] += __popcll(bal);
+          }
+        }
       }
-      if (lane == 0) s_cnt[h] = cnt;
+#pragma unroll
+      for (int h = 0; h < PNP_CHUNK; h++)
+        if (lane == 0 && h < nact) s_cnt[h] = cnts[h];
     }
     __syncthreads();
     PROF(13);
