@@ -1,6 +1,8 @@
 #!/bin/bash
 # Instruction budget of k_fast_cells by phase: VALU / SALU / LDS instruction counters and time alone of builds that skip phase A, B
 # (and everything after it) or C (-DFAST_SKIP_A/B/C: wrong results by design, counting only).   tools/fast_budget.sh
+# Build the three libraries first (in the build container):
+#   for v in A B C; do SD_OUT=tools/build/libsdslam_hip_skip$v.so SD_EXTRA_FLAGS=-DFAST_SKIP_$v python -m sdslam_amd.build --force; done
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
