@@ -402,12 +402,26 @@ __global__ __launch_bounds__(64 * W) void k_pose_opt(const sd_keypoint* __restri
       for (int i = tid; i < cap; i += PO_THREADS) match[i] = lm[i] >= 0 ? lm[i] + M : fm[i];
       __syncthreads();
     }
+    // r3: the edges of a wave's keypoints are dealt to its 64 lanes ROUND-ROBIN (ballot-ordered compaction: edge p of the wave goes to
+    // lane p % 64, slot p / 64).  Each lane used to keep the matched ones among ITS keypoints (i = tid + 64 k): with a quarter of the
+    // keypoints matched the longest list of a wave was about twice the mean, and the edge loops run to the longest list.
     int nInitial = 0;
-    for (int i0 = 0; i0 < nkp; i0 += PO_THREADS) {
-      const int i = i0 + tid;
-      const bool has = i < nkp && match[i] >= 0;
-      if (has) s_idx[my_edges++][tid] = (uint16_t)i;
-      nInitial += __popcll(__ballot(has));
+    {
+      const unsigned long long lt_ = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+      int wbase = 0;   // edges of this wave so far
+      for (int i0 = 0; i0 < nkp; i0 += PO_THREADS) {
+        const int i = i0 + tid;
+        const bool has = i < nkp && match[i] >= 0;
+        const unsigned long long bal = __ballot(has);
+        if (has) {
+          const int p = wbase + __popcll(bal & lt_);
+          s_idx[p >> 6][(wave << 6) + (p & 63)] = (uint16_t)i;
+        }
+        wbase += __popcll(bal);
+      }
+      nInitial = wbase;
+      my_edges = (wbase + 63 - lane) >> 6;   // positions p < wbase with p % 64 == lane
+      __syncthreads();   // the lists are written across lanes (one wave: a fence would do; with four waves block_count2 syncs anyway)
     }
     int max_edges = my_edges;   // longest list of the workgroup: uniform trip count of the edge loops
 #pragma unroll
