@@ -548,17 +548,20 @@ __device__ __forceinline__ void match_cand_frame(const int f, uint8_t* smem, con
     for (int c = tid; c <= GRID_COLS * GRID_ROWS; c += NT) g_cs[c] = s_cstart[c];
   }
   const MatchLds SL = {s_key, s_cstart, nullptr, nullptr, nullptr};
-  const int half = lane >> 5, glane = lane & 31;
-  const unsigned long long gm = 0xFFFFFFFFull << (32 * half);
-  const unsigned long long glt = ((1ull << glane) - 1ull) << (32 * half);
-  // ---- pass A: candidates per point (two points per wave, one per 32-lane half, as in k_match)
-  for (int i0 = 0; i0 < n_last; i0 += 2 * MT_WAVES) {
-    const int i = i0 + 2 * wave + half;
+  // r3: FOUR points per wave, one per 16-lane quarter (k_match: two).  A point's window is walked one grid-cell column at a time and a
+  // column's run holds 0...3 keypoints of the ~1000 spread over 64 x 48 cells: with 32 lanes per point nine tenths of them idled.
+  constexpr int CGL = 16, CPW = 64 / CGL;
+  const int half = lane / CGL, glane = lane % CGL;
+  const unsigned long long gm = ((1ull << CGL) - 1ull) << (CGL * half);
+  const unsigned long long glt = ((1ull << glane) - 1ull) << (CGL * half);
+  // ---- pass A: candidates per point
+  for (int i0 = 0; i0 < n_last; i0 += CPW * MT_WAVES) {
+    const int i = i0 + CPW * wave + half;
     if (i < n_last) {
       int cnt = 0;
       if ((s_valid[i >> 5] >> (i & 31)) & 1u) {
         int seq = 0;
-        cnt = (int)match_point<0, 32>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, nullptr, glane, glt, &seq, gm);
+        cnt = (int)match_point<0, CGL>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, nullptr, glane, glt, &seq, gm);
         if (cnt > 0 && seq >= 2048) cnt = 0xFFFF;   // (cnt itself is at most the keypoint count, < 0xFFFF)
       }
       if (glane == 0) s_cnt[i] = (uint16_t)cnt;
@@ -584,8 +587,8 @@ __device__ __forceinline__ void match_cand_frame(const int f, uint8_t* smem, con
   }
   __syncthreads();
   // ---- pass B: the keys, straight into the frame's HBM list
-  for (int i0 = 0; i0 < n_last; i0 += 2 * MT_WAVES) {
-    const int i = i0 + 2 * wave + half;
+  for (int i0 = 0; i0 < n_last; i0 += CPW * MT_WAVES) {
+    const int i = i0 + CPW * wave + half;
     if (i < n_last) {
       const int cnt = s_cnt[i];
       const uint32_t off = s_off[i];
@@ -594,7 +597,7 @@ __device__ __forceinline__ void match_cand_frame(const int f, uint8_t* smem, con
         pc = 0xFFFFFFFFu;   // evaluated by the assignment loop itself
       } else if (cnt > 0) {
         int seq = 0;
-        match_point<1, 32>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, g_list + off, glane, glt, &seq, gm);
+        match_point<1, CGL>(i, kps, desc, Xw, mp_desc, l_oct, uright, SL, G, cam, sf, g_list + off, glane, glt, &seq, gm);
         pc = (off << 16) | (uint32_t)cnt;
       }
       if (glane == 0) g_pt[i] = pc;
