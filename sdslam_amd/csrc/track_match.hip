@@ -550,7 +550,7 @@ __device__ __forceinline__ void match_cand_frame(const int f, uint8_t* smem, con
   const MatchLds SL = {s_key, s_cstart, nullptr, nullptr, nullptr};
   // r3: FOUR points per wave, one per 16-lane quarter (k_match: two).  A point's window is walked one grid-cell column at a time and a
   // column's run holds 0...3 keypoints of the ~1000 spread over 64 x 48 cells: with 32 lanes per point nine tenths of them idled.
-  constexpr int CGL = 16, CPW = 64 / CGL;
+  constexpr int CGL = 8, CPW = 64 / CGL;
   const int half = lane / CGL, glane = lane % CGL;
   const unsigned long long gm = ((1ull << CGL) - 1ull) << (CGL * half);
   const unsigned long long glt = ((1ull << glane) - 1ull) << (CGL * half);
