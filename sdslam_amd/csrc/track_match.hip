@@ -948,13 +948,15 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
   __syncthreads();   // also makes the o_* stores of this workgroup visible to its own later loads
   const MatchLds SL = {s_key, s_cstart, s_match, s_obs, s_kclaim};
   const bool bFactor = th != 1.0f;
-  // ---- phase 1: candidate lists, two points per wave (one per 32-lane half, see k_match)
+  // ---- phase 1: candidate lists, eight points per wave (one per 8-lane group, as in k_match_cand: a window column's run holds
+  // 0...3 keypoints)
   {
-    const int half = lane >> 5, glane = lane & 31;
-    const unsigned long long gm = 0xFFFFFFFFull << (32 * half);
-    const unsigned long long glt = ((1ull << glane) - 1ull) << (32 * half);
-    for (int i0 = 0; i0 < n_loc; i0 += 2 * MT_WAVES) {
-      const int i = i0 + 2 * wave + half;
+    constexpr int CGL = 8, CPW = 64 / CGL;
+    const int half = lane / CGL, glane = lane % CGL;
+    const unsigned long long gm = ((1ull << CGL) - 1ull) << (CGL * half);
+    const unsigned long long glt = ((1ull << glane) - 1ull) << (CGL * half);
+    for (int i0 = 0; i0 < n_loc; i0 += CPW * MT_WAVES) {
+      const int i = i0 + CPW * wave + half;
       if (i < n_loc) {
         uint32_t pc = 0;
         if (o_inview[i]) {
@@ -963,16 +965,16 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match_local(const sd_keypoint
           const int lvl = o_level[i];
           const float radius = r * sf[lvl];
           int seq = 0;
-          const int cnt = (int)match_window<0, 32>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], radius, lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
+          const int cnt = (int)match_window<0, CGL>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], radius, lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
                                                    mp_desc + (size_t)i * 32, kps, desc, uright, SL, cam, invW, invH, nullptr, glane, glt, &seq, -1, gm);
           if (cnt > 0) {
             int off = 0;
             if (glane == 0) off = atomicAdd(s_nlist, cnt);
-            off = __shfl(off, 32 * half);
+            off = __shfl(off, CGL * half);
             if (off + cnt > MT_LIST_CAP || seq >= 2048 || cnt > 0xffff) {
               pc = 0xFFFFFFFFu;
             } else {
-              match_window<1, 32>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], radius, lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
+              match_window<1, CGL>(o_proj[(size_t)i * 3], o_proj[(size_t)i * 3 + 1], radius, lvl - 1, lvl, o_proj[(size_t)i * 3 + 2],
                                   mp_desc + (size_t)i * 32, kps, desc, uright, SL, cam, invW, invH, s_list + off, glane, glt, &seq, -1, gm);
               pc = ((uint32_t)off << 16) | (uint32_t)cnt;
             }
