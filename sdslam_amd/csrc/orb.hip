@@ -1101,6 +1101,8 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 #ifndef DESC_KPW
 #define DESC_KPW 2   // keypoints per wave
 #endif
+#define DESC_PATCH_LD 6                       // dword loads per lane and keypoint: 6 x 64 >= 37 rows x 10 dwords
+#define DESC_PATCH_DW (DESC_PATCH_LD * 64)
 __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr,
                                                      const uint8_t* __restrict__ blur,
                                                      const uint32_t* __restrict__ sel,
@@ -1160,6 +1162,27 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
   }
   if (!live[0]) return;   // slots are filled in order: no first keypoint, no second
 
+  // ---- the blurred 37 x 37 patch of each keypoint (the rotated test points reach +-18) goes to LDS as 37 rows of ten aligned
+  // dwords, fetched NOW, beside the IC_Angle rows: the 512 sample reads of a keypoint were byte gathers over ~30 cache lines
+  // per instruction that could only start once the angle was known
+  __shared__ uint32_t s_patch[4][DESC_KPW][DESC_PATCH_DW];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t pdw[DESC_KPW][DESC_PATCH_LD];
+  int psh[DESC_KPW];
+#pragma unroll
+  for (int q = 0; q < DESC_KPW; q++) {
+    const uint8_t* a = bbase[q] + step[q] + 1;            // pixel (X - 18, Y - 18)
+    psh[q] = (int)((uintptr_t)a & 3);
+    const uint8_t* a4 = a - psh[q];
+#pragma unroll
+    for (int k = 0; k < DESC_PATCH_LD; k++) {
+      const int e = min(k * 64 + lane, 37 * 10 - 1);
+      const int row = (int)(((unsigned)e * 6554u) >> 16);   // e / 10, e < 16384
+      const int d = e - row * 10;
+      pdw[q][k] = *(const uint32_t*)(a4 + (uint32_t)(__mul24(row, step[q]) + 4 * d));
+    }
+  }
+
   // ---- IC_Angle: m10 = sum u * I, m01 = sum v * I over the disc.  Lane = (column u, half): the lower half of the wave walks
   // the rows +v, the upper half the rows -v; per row one load per keypoint, u * (sum of the column) and +-(sum of v * I) at
   // the end (integer sums: any order is exact).
@@ -1190,6 +1213,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
         off[q] += (uint32_t)dstep[q];
       }
     }
+#pragma unroll
+    for (int q = 0; q < DESC_KPW; q++)
+#pragma unroll
+      for (int k = 0; k < DESC_PATCH_LD; k++) s_patch[wv][q][k * 64 + lane] = pdw[q][k];
     int vlim = -1;   // largest row index of this lane's column inside the disc (-1: lane outside)
 #pragma unroll
     for (int v = 0; v <= 15; v++) vlim += (act && au <= kUmax[v]) ? 1 : 0;
@@ -1227,9 +1254,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
   }
   // ---- steered rBRIEF on the blurred level
   unsigned long long words[DESC_KPW][4];
-  int c19[DESC_KPW];
-#pragma unroll
-  for (int q = 0; q < DESC_KPW; q++) c19[q] = 19 * step[q] + 19;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own patch stores before its sample reads
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int t = j * 64 + lane;
@@ -1242,8 +1267,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
       // center[cvRound(x*b + y*a)*step + cvRound(x*a - y*b)]
       const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
       const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
-      t0[q] = bbase[q][(uint32_t)(__mul24(r0, step[q]) + q0 + c19[q])];
-      t1[q] = bbase[q][(uint32_t)(__mul24(r1, step[q]) + q1 + c19[q])];
+      const uint8_t* pb = (const uint8_t*)s_patch[wv][q] + (18 * 40 + 18 + psh[q]);
+      t0[q] = pb[__mul24(r0, 40) + q0];
+      t1[q] = pb[__mul24(r1, 40) + q1];
     }
 #pragma unroll
     for (int q = 0; q < DESC_KPW; q++) words[q][j] = __builtin_amdgcn_ballot_w64(t0[q] < t1[q]);
