@@ -971,6 +971,7 @@ __global__ __launch_bounds__(64) void k_select_final(const OrbPlan* __restrict__
 // (the blurred image is not an output), which frees the stage from waiting for the selection.
 // ------------------------------------------------------------------------------------------
 #define BLUR_RB 32                  // output rows per wave
+#define SD_BLUR_SHIFT 1             // column offset of the blurred levels against the pyramid's layout (see k_blur)
 #define BLUR_TW 256                 // output columns per workgroup (64 lanes x 4)
 #define BLUR_TH (4 * BLUR_RB)       // output rows per workgroup (4 waves)
 #ifndef BLUR_PF
@@ -992,7 +993,9 @@ __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, con
   const size_t fo = (size_t)frame * P->pyr_frame_bytes + L.off;
   // input bytes for outputs x0..x0+3: padded columns x0+16 .. x0+27 (4-byte aligned)
   const uint8_t* src = pyr + fo + (size_t)(y0 + SD_EDGE - 3) * L.pstride + (x0 + SD_EDGE - 3);
-  uint8_t* dst = blur + fo + (size_t)(y0 + SD_EDGE) * L.pstride + (x0 + SD_EDGE);
+  // the blurred level sits ONE column to the right of the pyramid's layout (interior from padded column 20: its rows have the
+  // room, and nothing reads its border): a lane's four output pixels are then an aligned dword
+  uint8_t* dst = blur + fo + (size_t)(y0 + SD_EDGE) * L.pstride + (x0 + SD_EDGE + SD_BLUR_SHIFT);
   const int nrows = min(BLUR_RB, L.h - y0);
   const bool full = x0 + 3 < L.w;
   // Row pass: out[k] = sum_i tap[i] * byte[k + i] as two v_dot4_u32_u8 over byte windows cut out of the three dwords with
@@ -1049,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, con
         const uint32_t packed = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
         uint8_t* o = dst + (size_t)(r - 6) * L.pstride;
         if (full) {
-          __builtin_memcpy(o, &packed, 4);   // interior starts at padded column 19: 4-byte store, 1-byte aligned
+          *(uint32_t*)o = packed;
         } else {
           for (int k = 0; k < 4; k++)
             if (x0 + k < L.w) o[k] = (uint8_t)(packed >> (8 * k));
@@ -1158,7 +1161,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
     kpsize[q] = L.kpsize;
     const size_t fo = (size_t)frame * P->pyr_frame_bytes + L.off + (size_t)(Y[q] + SD_EDGE - 19) * L.pstride + X[q] + SD_EDGE - 19;
     pbase[q] = pyr + fo;
-    bbase[q] = blur + fo;
+    bbase[q] = blur + fo + SD_BLUR_SHIFT;
   }
   if (!live[0]) return;   // slots are filled in order: no first keypoint, no second
 
@@ -2035,7 +2038,7 @@ int sd_orb_level_copy(sd_orb* h, int frame, int level, int padded, uint8_t* out,
 
 int sd_orb_debug_blurred(sd_orb* h, int frame, int level, uint8_t* out, int out_stride) {
   SD_REQUIRE(h, SD_ERR_INVALID_ARG, "handle is NULL");
-  return copy_level(h, h->d_blur, frame, level, 0, out, out_stride);
+  return copy_level(h, h->d_blur + SD_BLUR_SHIFT, frame, level, 0, out, out_stride);
 }
 
 int sd_orb_debug_cell_counts(sd_orb* h, int frame, int level, int32_t* out, int cap, int* n_cells) {

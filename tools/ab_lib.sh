@@ -8,4 +8,4 @@ python -m pytest tests/test_orb_gpu.py tests/test_golden.py -q -m gpu -x --no-he
 tail -1 gpurun_out/${TAG}_t.log
 bash tools/ab_bench.sh ${TAG} 3 "" "" "SD_LIB=tools/build/libsdslam_hip_base.so"
 bash tools/ab_bench.sh ${TAG}orb 2 "--orb-only" "--orb-only" "SD_LIB=tools/build/libsdslam_hip_base.so"
-bash tools/trace_quick.sh ${TAG} | head -14
+bash tools/trace_quick.sh ${TAG} > gpurun_out/${TAG}_tq.txt; head -14 gpurun_out/${TAG}_tq.txt
