@@ -972,8 +972,6 @@ __global__ __launch_bounds__(64) void k_select_final(const OrbPlan* __restrict__
 // ------------------------------------------------------------------------------------------
 #define BLUR_RB 32                  // output rows per wave
 #define SD_BLUR_SHIFT 1             // column offset of the blurred levels against the pyramid's layout (see k_blur)
-#define BLUR_TW 256                 // output columns per workgroup (64 lanes x 4)
-#define BLUR_TH (4 * BLUR_RB)       // output rows per workgroup (4 waves)
 #ifndef BLUR_PF
 #define BLUR_PF 6                   // input rows in flight per thread
 #endif
@@ -987,8 +985,13 @@ __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, con
   const int frame = (int)uframe, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   (void)sel_count;   // every level is blurred: the stage then depends on the pyramid only and overlaps FAST/selection
   const LevelGeom L = P->lv[T.level];
-  const int x0 = T.tx * BLUR_TW + lane * 4;
-  const int y0 = T.ty * BLUR_TH + wave * BLUR_RB;
+  // r3: the level is cut into 64-column strips x 32-row bands and the (strip, band) pairs are dealt FLAT to 16-lane groups (strip
+  // fastest: the four groups of a wave read 256 contiguous columns wherever the level is that wide).  With a whole wave per 256
+  // columns the levels' widths (640, 533, 444, 370, 309, 257, 214, 179) left a quarter of all lanes without a column.
+  const int pr = T.p0 + wave * 4 + (lane >> 4);
+  const int band = (int)__umulhi((unsigned)pr, T.magic), strip = pr - band * T.nstrips;
+  const int x0 = strip * 64 + (lane & 15) * 4;
+  const int y0 = band * BLUR_RB;
   if (x0 >= L.w || y0 >= L.h) return;
   const size_t fo = (size_t)frame * P->pyr_frame_bytes + L.off;
   // input bytes for outputs x0..x0+3: padded columns x0+16 .. x0+27 (4-byte aligned)

@@ -242,8 +242,11 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
     L.cand_cap = cand - L.cand_off;
     hp.max_cells_per_level = std::max(hp.max_cells_per_level, L.ncells);
 
-    for (int ty = 0; ty < (L.h + 127) / 128; ty++)      // k_blur: 256 x 128 output tiles
-      for (int tx = 0; tx < (L.w + 255) / 256; tx++) hp.blur_tiles.push_back(BlurTile{l, tx, ty});
+    {   // k_blur: a 16-lane group per (64-column strip, 32-row band), sixteen groups per workgroup, dealt flat over the level
+      const int nstrips = (L.w + 63) / 64, npairs = nstrips * ((L.h + 31) / 32);
+      for (int p0 = 0; p0 < npairs; p0 += 16)
+        hp.blur_tiles.push_back(BlurTile{l, p0, nstrips, (unsigned)(0xFFFFFFFFull / (unsigned)nstrips) + 1u});
+    }
   }
   P.ncells = (int)hp.cells.size();
   P.nsel = sel;

@@ -44,7 +44,8 @@ struct CellGeom {
   int evaluated;         // 0: the reference `continue`s over this cell (never calls FAST)
 };
 
-struct BlurTile { int level, tx, ty; };
+// k_blur work item: 16 consecutive (64-column strip, 32-row band) pairs of a level, pair p = band * nstrips + strip
+struct BlurTile { int level, p0, nstrips; unsigned magic; };   // magic: p / nstrips == umulhi(p, magic)
 
 struct OrbPlan {
   int nlevels, ncells, nsel;   // nsel = sum of quotas (<= nfeatures)
