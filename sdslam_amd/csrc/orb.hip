@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_pyr_level(const LevelGeom L, const Leve
 __device__ __forceinline__ void pyr_resize_body(const LevelGeom& L, const LevelGeom& S, size_t pyr_frame_bytes, int level,
                                                 const int32_t* __restrict__ coef, const uint8_t* __restrict__ src0, int src_stride,
                                                 size_t src_frame_stride, uint8_t* __restrict__ pyr, int G, unsigned magicG, int Hh,
-                                                int frame, unsigned e) {
+                                                int frame, unsigned e, int mirror) {
   const unsigned Y0 = __umulhi(e, magicG);        // e / G
   if (Y0 >= (unsigned)Hh) return;
   const int g = (int)(e - Y0 * (unsigned)G);
@@ -295,10 +295,17 @@ __device__ __forceinline__ void pyr_resize_body(const LevelGeom& L, const LevelG
   int Yr[PYR_RPT], PY[PYR_RPT];   // interior (source-side) row, padded (destination) row
 #pragma unroll
   for (int r = 0; r < PYR_RPT; r++) {
-    PY[r] = (int)Y0 + r * Hh;
-    live[r] = PY[r] < L.prows;
-    if (!live[r]) PY[r] = (int)Y0;   // duplicate work, not stored
-    Yr[r] = reflect101(PY[r] - SD_EDGE, L.h);
+    if (mirror) {   // interior rows only: the border rows are second stores of their REFLECT_101 source rows (below)
+      Yr[r] = (int)Y0 + r * Hh;
+      live[r] = Yr[r] < L.h;
+      if (!live[r]) Yr[r] = (int)Y0;   // duplicate work, not stored
+      PY[r] = Yr[r] + SD_EDGE;
+    } else {
+      PY[r] = (int)Y0 + r * Hh;
+      live[r] = PY[r] < L.prows;
+      if (!live[r]) PY[r] = (int)Y0;   // duplicate work, not stored
+      Yr[r] = reflect101(PY[r] - SD_EDGE, L.h);
+    }
   }
   if (level == 0) {
 #pragma unroll
@@ -373,9 +380,22 @@ __device__ __forceinline__ void pyr_resize_body(const LevelGeom& L, const LevelG
       packed[r] = pk;
     }
   }
+  // r3: the top / bottom REFLECT_101 border rows are COPIES of interior rows of the same level (copyMakeBorder after resize,
+  // src/ORBextractor.cc:693-696): padded row 19 - Y holds row Y (1 <= Y <= 19), padded row 2 h + 17 - Y holds row Y
+  // (h - 20 <= Y <= h - 2).  With `mirror` a thread's rows are interior rows and the thread that has just computed a pixel group
+  // of such a row stores it a second time, instead of 38 more rows of full resize work per level (9 % of level 1, 22 % of level 7).
+  // (The same for the border COLUMNS -- byte-reversed second stores by the threads at both ends of a row -- was built and lost:
+  // nearly every wave holds a row end, and its 30-40 extra partial-lane store instructions cost more than the edge workgroups.)
 #pragma unroll
-  for (int r = 0; r < PYR_RPT; r++)
-    if (live[r]) *(uint32_t*)(dstb + (dst_x + (uint32_t)__mul24(PY[r], L.pstride))) = packed[r];
+  for (int r = 0; r < PYR_RPT; r++) {
+    if (!live[r]) continue;
+    *(uint32_t*)(dstb + (dst_x + (uint32_t)__mul24(PY[r], L.pstride))) = packed[r];
+    if (mirror) {
+      const int Yi = Yr[r];
+      const int prow2 = Yi >= 1 && Yi <= SD_EDGE ? SD_EDGE - Yi : (Yi >= L.h - 20 && Yi <= L.h - 2 ? 2 * L.h + 17 - Yi : -1);
+      if (prow2 >= 0) *(uint32_t*)(dstb + (dst_x + (uint32_t)__mul24(prow2, L.pstride))) = packed[r];
+    }
+  }
 }
 
 // all padded rows: padded columns [0, 20) and [20 + 4 G, roundup4(w + 38)); one thread per 4 columns
@@ -394,16 +414,18 @@ __device__ __forceinline__ void pyr_edges_body(const LevelGeom& L, const LevelGe
 __global__ __launch_bounds__(256) void k_pyr_split(const LevelGeom L, const LevelGeom S, size_t pyr_frame_bytes, int level,
                                                    const int32_t* __restrict__ coef, const uint8_t* __restrict__ src0, int src_stride,
                                                    size_t src_frame_stride, uint8_t* __restrict__ pyr, int G, unsigned magicG, int Hh,
-                                                   int T, unsigned magicT, unsigned n_resize) {
+                                                   int T, unsigned magicT, unsigned n_resize, int mirror) {
   unsigned uframe, bx;
   xcd_frame_block(uframe, bx);
   const int frame = (int)uframe;
   if (bx < n_resize)
     pyr_resize_body(L, S, pyr_frame_bytes, level, coef, src0, src_stride, src_frame_stride, pyr, G, magicG, Hh, frame,
-                    bx * 256 + threadIdx.x);
+                    bx * 256 + threadIdx.x, mirror);
+#ifndef PYR_SKIP_EDGES
   else
     pyr_edges_body(L, S, pyr_frame_bytes, level, src0, src_stride, src_frame_stride, pyr, G, T, magicT, frame,
                    (bx - n_resize) * 256 + threadIdx.x);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1523,11 +1545,12 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
     } else {
     auto magic = [](unsigned d) { return (unsigned)(0xFFFFFFFFull / d) + 1u; };   // e / d == umulhi(e, magic) for e < 2^31 / d
     const int G = (L.w - 1) / 4;
+    const bool mirror = L.h >= 48;   // border rows as second stores of their source rows (single reflections)
     const int T = 5 + (((L.w + 2 * SD_EDGE + 3) & ~3) - 20 - 4 * G) / 4;
-    const int Hh = (L.prows + PYR_RPT - 1) / PYR_RPT;   // padded rows per row-slot of a thread
+    const int Hh = ((mirror ? L.h : L.prows) + PYR_RPT - 1) / PYR_RPT;   // (padded) rows per row-slot of a thread
     const unsigned n_resize = (unsigned)(((size_t)Hh * G + 255) / 256), n_edges = (unsigned)(((size_t)L.prows * T + 255) / 256);
     hipLaunchKernelGGL(k_pyr_split, dim3(n_resize + n_edges, n), dim3(256), 0, ps, L, S, (size_t)P.pyr_frame_bytes, l, h->d_coef, d_imgs,
-                       stride, frame_stride, h->d_pyr, G, magic((unsigned)G), Hh, T, magic((unsigned)T), n_resize);
+                       stride, frame_stride, h->d_pyr, G, magic((unsigned)G), Hh, T, magic((unsigned)T), n_resize, mirror ? 1 : 0);
     }
     // FAST of this level starts now, on its own stream
     // levels >= merge_from share ONE launch after the last level is complete (cells of consecutive levels are contiguous)
