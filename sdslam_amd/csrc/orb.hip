@@ -5,7 +5,7 @@
 // all frames of a batch (and, for blur / selection / descriptors, all pyramid levels).
 //
 //   k_pyr_split      ComputePyramid: resize + copyMakeBorder   src/ORBextractor.cc:680-700 (one launch per level: aligned 4-pixel
-//                    groups of every padded row, table-driven bilinear | left / right REFLECT_101 borders + unaligned remainder)
+//                    groups of every padded row, table-driven bilinear at REFLECT_101 column indices; border rows as second stores)
 //   k_pyr_level      same, single generic pass     (exact-2x INTER_AREA levels, byte-unaligned inputs, tiny levels)
 //   k_fast_cells     cv::FAST per grid cell        src/ORBextractor.cc:501-552 (FAST-9/16, score, cell-local 3x3 NMS)
 //   k_select_*       quota loop + retainBest       src/ORBextractor.cc:554-605 (wave-parallel libstdc++ introselect replay)
@@ -263,13 +263,11 @@ __global__ __launch_bounds__(256) void k_pyr_level(const LevelGeom L, const Leve
 // ------------------------------------------------------------------------------------------
 // Split pyramid construction (the default path).  k_pyr_level above evaluates every padded pixel
 // through one code path, so the waves at both ends of a row run the slow reflected-border branch
-// as well as the interior one.  Here:
-//   resize role   aligned 4-pixel groups (padded columns 20 + 4g) of every padded row, no column reflection, no
-//                 divergence: coefficient tables (the host's cv::resize tables), one aligned
-//                 12-byte window per source row, v_perm_b32 gathers the 2 x 4 source bytes;
-//   edges role    the few interior pixels left of / right of the aligned groups and the left /
-//                 right REFLECT_101 borders of every padded row, via pyr_px4 (generic path).
-// Level 0 is the frame copied into the padded layout by the same kernel.
+// as well as the interior one.  Here every thread owns an aligned 4-pixel group (padded columns 4 gi ... 4 gi + 3) of three rows:
+// coefficient tables (the host's cv::resize tables) read at the REFLECT_101 column index of each pixel, one aligned 12-byte window
+// per source row (the four sources of a group lie within 8 bytes whatever their order), v_perm_b32 gathers the 2 x 4 source bytes.
+// (r1-r3 had a second role for the border columns and the interior pixels outside the aligned interior groups, on the generic
+// per-byte path pyr_px4: a fifth of every launch's workgroups.)  Level 0 is the frame copied into the padded layout by the same kernel.
 // ------------------------------------------------------------------------------------------
 #ifndef PYR_RPT
 #define PYR_RPT 3
@@ -277,16 +275,24 @@ __global__ __launch_bounds__(256) void k_pyr_level(const LevelGeom L, const Leve
 // rows per thread: rows Y, Y + ceil(h / 3), Y + 2 ceil(h / 3) share the x coefficients and give three independent load chains
 // (A/B on one box, full step: 3 rows 130.8 k, 2 rows 130.4 k frames/s; 4 rows were no better than 2 in r01i)
 // **r2**: the rows are PADDED rows (0 .. h + 37): a top / bottom border row is the resize of its REFLECT_101 interior row, computed
-// here like any other row instead of being copied by a third kernel after the first two (k_pyr_rows, gone); with that the two
-// remaining roles are independent and share ONE launch per level (k_pyr_split): 8 pyramid launches per step instead of 24.
+// here like any other row instead of being copied by a third kernel after the first two (k_pyr_rows, gone): ONE launch per level
+// (k_pyr_split), 8 pyramid launches per step instead of 24.  r3: where the level is tall enough for single reflections the border
+// rows are second stores of their source rows (`mirror`).
 __device__ __forceinline__ void pyr_resize_body(const LevelGeom& L, const LevelGeom& S, size_t pyr_frame_bytes, int level,
                                                 const int32_t* __restrict__ coef, const uint8_t* __restrict__ src0, int src_stride,
                                                 size_t src_frame_stride, uint8_t* __restrict__ pyr, int G, unsigned magicG, int Hh,
                                                 int frame, unsigned e, int mirror) {
   const unsigned Y0 = __umulhi(e, magicG);        // e / G
   if (Y0 >= (unsigned)Hh) return;
-  const int g = (int)(e - Y0 * (unsigned)G);
-  const int X0 = 1 + 4 * g;
+  // r3: G counts the 4-pixel groups of the whole PADDED row (padded columns 4 gi ... 4 gi + 3, gi = 0 ... G - 1): the border columns and
+  // the few interior pixels outside the aligned interior groups go through the same code at their REFLECT_101 column positions
+  // (their four sources still lie within one 8-byte window, in any order) instead of a second role on the generic per-byte path,
+  // which was a fifth of every launch's workgroups.  Everything that depends on the group alone -- window base, v_perm selectors,
+  // coefficient pairs, the level-0 copy's source column and byte order -- comes from a host-built table (orb_plan.cpp group_table:
+  // three aligned 16-byte loads), so the kernel does no reflection, minimum or selector arithmetic.
+  const int gi = (int)(e - Y0 * (unsigned)G);
+  const int X0 = 4 * gi - SD_EDGE;   // first pixel of the group; negative / beyond w - 1: border
+  const int4* gt = (const int4*)(coef + L.cg) + 3 * gi;
   // wave-uniform base pointers + 32-bit per-lane offsets: loads and stores use the SGPR-base addressing form
   uint8_t* dstb = pyr + (size_t)frame * pyr_frame_bytes + L.off;
   const uint32_t dst_x = (uint32_t)(X0 + SD_EDGE);
@@ -312,33 +318,39 @@ __device__ __forceinline__ void pyr_resize_body(const LevelGeom& L, const LevelG
     for (int r = 0; r < PYR_RPT; r++) {
       // k_pyr_resize runs for level 0 only when base pointer and strides are 4-byte aligned (pipeline_body)
       const uint8_t* s = src0 + (size_t)frame * src_frame_stride;
-      const uint32_t o = (uint32_t)(__mul24(Yr[r], src_stride) + X0);
+      // (computed, not read from the group table: the copy is latency-bound and the table would be one more dependent round trip)
+      int Xr[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (L.w >= 64) {   // single reflection, branch-free (columns beyond the padded width, whose result is dropped, are clamped)
+          int x = X0 + k;
+          x = x < 0 ? -x : x;
+          x = x >= L.w ? 2 * L.w - 2 - x : x;
+          Xr[k] = max(x, 0);
+        } else {
+          Xr[k] = reflect101(X0 + k, L.w);
+        }
+      }
+      const int Xmin = min(min(Xr[0], Xr[1]), min(Xr[2], Xr[3]));   // the four sources are Xmin ... Xmin + 3 in some order
+      const uint32_t sel = (uint32_t)(Xr[0] - Xmin) | (uint32_t)(Xr[1] - Xmin) << 8 | (uint32_t)(Xr[2] - Xmin) << 16 | (uint32_t)(Xr[3] - Xmin) << 24;
+      const uint32_t o = (uint32_t)(__mul24(Yr[r], src_stride) + Xmin);
       const uint32_t* q = (const uint32_t*)(s + (o & ~3u));
-      packed[r] = __builtin_amdgcn_alignbyte(q[1], q[0], o & 3u);
+      // (the second dword is not fetched where it would start beyond the row's last pixel: nothing in it is selected, and the
+      // last row of the last frame has nothing behind it)
+      const uint32_t last = (uint32_t)(__mul24(Yr[r], src_stride) + L.w - 1);
+      const uint32_t q1 = q[((o & 3u) != 0u && (o & ~3u) + 4u <= last) ? 1 : 0];
+      packed[r] = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(q1, q[0], o & 3u), sel);
     }
   } else {
-    const int32_t* xo = coef + L.cx;
-    const int32_t* xa = xo + L.w;
     const int32_t* yo = coef + L.cy;
     const int32_t* yb = yo + L.h;
-    int sx[4];
-    uint32_t ab[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      sx[k] = xo[(uint32_t)(X0 + k)];
-      ab[k] = (uint32_t)xa[(uint32_t)(X0 + k)];
-    }
-    const int base = sx[0];
+    const int4 t0 = gt[0], t1 = gt[1], t2 = gt[2];
+    const int base = t0.x;
     // v_perm selector per output pixel: {left source byte, 0, right source byte, 0} of the row's 8-byte window = the two
     // taps as a u16 pair, which v_dot2_u32_u16 multiplies with the packed coefficient pair ab[k] in one instruction
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    uint32_t selP[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int o = sx[k] - base;
-      const int o1 = (sx[k] + 1 < S.w ? sx[k] + 1 : S.w - 1) - base;
-      selP[k] = (uint32_t)o | 0x0c00u | ((uint32_t)o1 << 16) | 0x0c000000u;
-    }
+    const uint32_t selP[4] = {(uint32_t)t0.y, (uint32_t)t0.z, (uint32_t)t0.w, (uint32_t)t1.x};
+    const uint32_t ab[4] = {(uint32_t)t1.y, (uint32_t)t1.z, (uint32_t)t1.w, (uint32_t)t2.x};
     const uint8_t* sb = pyr + (size_t)frame * pyr_frame_bytes + S.off;   // 64-byte aligned (level offsets and row pitches are)
     uint32_t u[PYR_RPT][3], v[PYR_RPT][3], bbv[PYR_RPT];
     unsigned shv[PYR_RPT];
@@ -374,8 +386,9 @@ __device__ __forceinline__ void pyr_resize_body(const LevelGeom& L, const LevelG
         const int h0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(r0hi, r0lo, selP[k])), w, 0u, false);
         const int h1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(r1hi, r1lo, selP[k])), w, 0u, false);
         // (b * (h >> 4)) >> 16 == mulhi(b << 12, h & ~15): one 32-bit multiply per source row (b <= 2048, h < 2^20)
-        const int ov = (int)(__umulhi((uint32_t)b0 << 12, (uint32_t)h0 & ~15u) + __umulhi((uint32_t)b1 << 12, (uint32_t)h1 & ~15u) + 2u) >> 2;
-        pk |= (uint32_t)(ov < 0 ? 0 : (ov > 255 ? 255 : ov)) << (8 * k);
+        // no saturation needed: a0 + a1 = b0 + b1 = 2048, so h <= 255 * 2048 and the sum below is at most (2048 * 32640 >> 16) + 2 = 1022
+        const uint32_t ov = (__umulhi((uint32_t)b0 << 12, (uint32_t)h0 & ~15u) + __umulhi((uint32_t)b1 << 12, (uint32_t)h1 & ~15u) + 2u) >> 2;
+        pk |= ov << (8 * k);
       }
       packed[r] = pk;
     }
@@ -386,9 +399,13 @@ __device__ __forceinline__ void pyr_resize_body(const LevelGeom& L, const LevelG
   // of such a row stores it a second time, instead of 38 more rows of full resize work per level (9 % of level 1, 22 % of level 7).
   // (The same for the border COLUMNS -- byte-reversed second stores by the threads at both ends of a row -- was built and lost:
   // nearly every wave holds a row end, and its 30-40 extra partial-lane store instructions cost more than the edge workgroups.)
+  // columns beyond the padded width (the last group of a row when w + 38 is not a multiple of 4) stay zero
+  const int nvalid = L.w + 2 * SD_EDGE - (int)dst_x;
+  const uint32_t keep = nvalid >= 4 ? 0xffffffffu : (1u << (8 * nvalid)) - 1u;
 #pragma unroll
   for (int r = 0; r < PYR_RPT; r++) {
     if (!live[r]) continue;
+    packed[r] &= keep;
     *(uint32_t*)(dstb + (dst_x + (uint32_t)__mul24(PY[r], L.pstride))) = packed[r];
     if (mirror) {
       const int Yi = Yr[r];
@@ -398,34 +415,15 @@ __device__ __forceinline__ void pyr_resize_body(const LevelGeom& L, const LevelG
   }
 }
 
-// all padded rows: padded columns [0, 20) and [20 + 4 G, roundup4(w + 38)); one thread per 4 columns
-__device__ __forceinline__ void pyr_edges_body(const LevelGeom& L, const LevelGeom& S, size_t pyr_frame_bytes, int level,
-                                               const uint8_t* __restrict__ src0, int src_stride, size_t src_frame_stride,
-                                               uint8_t* __restrict__ pyr, int G, int T, unsigned magicT, int frame, unsigned e) {
-  const unsigned py = __umulhi(e, magicT);        // e / T
-  if (py >= (unsigned)L.prows) return;
-  const int j = (int)(e - py * (unsigned)T);
-  const int px = j < 5 ? 4 * j : 20 + 4 * G + 4 * (j - 5);
-  const uint32_t v = pyr_px4(L, S, pyr_frame_bytes, level, frame, px, (int)py, src0, src_stride, src_frame_stride, pyr);
-  *(uint32_t*)(pyr + (size_t)frame * pyr_frame_bytes + L.off + (size_t)py * L.pstride + px) = v;
-}
-
-// one launch per level: workgroups [0, n_resize) run the aligned-group resize, the rest the edge columns
+// one launch per level
 __global__ __launch_bounds__(256) void k_pyr_split(const LevelGeom L, const LevelGeom S, size_t pyr_frame_bytes, int level,
                                                    const int32_t* __restrict__ coef, const uint8_t* __restrict__ src0, int src_stride,
                                                    size_t src_frame_stride, uint8_t* __restrict__ pyr, int G, unsigned magicG, int Hh,
-                                                   int T, unsigned magicT, unsigned n_resize, int mirror) {
+                                                   int mirror) {
   unsigned uframe, bx;
   xcd_frame_block(uframe, bx);
-  const int frame = (int)uframe;
-  if (bx < n_resize)
-    pyr_resize_body(L, S, pyr_frame_bytes, level, coef, src0, src_stride, src_frame_stride, pyr, G, magicG, Hh, frame,
-                    bx * 256 + threadIdx.x, mirror);
-#ifndef PYR_SKIP_EDGES
-  else
-    pyr_edges_body(L, S, pyr_frame_bytes, level, src0, src_stride, src_frame_stride, pyr, G, T, magicT, frame,
-                   (bx - n_resize) * 256 + threadIdx.x);
-#endif
+  pyr_resize_body(L, S, pyr_frame_bytes, level, coef, src0, src_stride, src_frame_stride, pyr, G, magicG, Hh, (int)uframe,
+                  bx * 256 + threadIdx.x, mirror);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1538,19 +1536,18 @@ static int pipeline_body(sd_orb* h, const uint8_t* d_imgs, int n, int stride, si
   for (int l = 0; l < P.nlevels; l++) {
     const LevelGeom& L = P.lv[l];
     const LevelGeom& S = P.lv[l > 0 ? l - 1 : 0];
-    const bool split = L.w >= 16 && (l == 0 ? src_aligned : L.fast_resize != 0);
+    const bool split = L.w >= 16 && L.fast_resize != 0 && (l > 0 || src_aligned);
     if (!split) {   // generic single-pass kernel (exact-2x INTER_AREA levels, odd source alignment, tiny levels)
       dim3 grid((L.pstride + 255) / 256, (L.prows + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), n), block(64, 4, 1);
       hipLaunchKernelGGL(k_pyr_level, grid, block, 0, ps, L, S, (size_t)P.pyr_frame_bytes, l, d_imgs, stride, frame_stride, h->d_pyr);
     } else {
     auto magic = [](unsigned d) { return (unsigned)(0xFFFFFFFFull / d) + 1u; };   // e / d == umulhi(e, magic) for e < 2^31 / d
-    const int G = (L.w - 1) / 4;
+    const int G = (L.w + 2 * SD_EDGE + 3) / 4;   // 4-pixel groups of a padded row
     const bool mirror = L.h >= 48;   // border rows as second stores of their source rows (single reflections)
-    const int T = 5 + (((L.w + 2 * SD_EDGE + 3) & ~3) - 20 - 4 * G) / 4;
     const int Hh = ((mirror ? L.h : L.prows) + PYR_RPT - 1) / PYR_RPT;   // (padded) rows per row-slot of a thread
-    const unsigned n_resize = (unsigned)(((size_t)Hh * G + 255) / 256), n_edges = (unsigned)(((size_t)L.prows * T + 255) / 256);
-    hipLaunchKernelGGL(k_pyr_split, dim3(n_resize + n_edges, n), dim3(256), 0, ps, L, S, (size_t)P.pyr_frame_bytes, l, h->d_coef, d_imgs,
-                       stride, frame_stride, h->d_pyr, G, magic((unsigned)G), Hh, T, magic((unsigned)T), n_resize, mirror ? 1 : 0);
+    const unsigned n_resize = (unsigned)(((size_t)Hh * G + 255) / 256);
+    hipLaunchKernelGGL(k_pyr_split, dim3(n_resize, n), dim3(256), 0, ps, L, S, (size_t)P.pyr_frame_bytes, l, h->d_coef, d_imgs,
+                       stride, frame_stride, h->d_pyr, G, magic((unsigned)G), Hh, mirror ? 1 : 0);
     }
     // FAST of this level starts now, on its own stream
     // levels >= merge_from share ONE launch after the last level is complete (cells of consecutive levels are contiguous)

@@ -65,6 +65,50 @@ static void resize_tables(int sn, int dn, std::vector<int32_t>& ofs, std::vector
   }
 }
 
+// k_pyr_split's per-group table: for every aligned 4-pixel group of a PADDED row (padded columns 4 gi ... 4 gi + 3, pixels
+// X0 + k with X0 = 4 gi - 19 at their REFLECT_101 positions) {base = smallest source column, 4 v_perm selectors (left / right tap
+// relative to base), 4 coefficient pairs, Xmin and byte selector of the level-0 copy, 0}: the kernel does no reflection, minimum
+// or selector arithmetic of its own.  Returns false if some group's sources do not fit the 8-byte window.
+static bool group_table(LevelGeom& L, int src_w, const std::vector<int32_t>* xo, const std::vector<int32_t>* xa, std::vector<int32_t>& coef) {
+  while (coef.size() % 4) coef.push_back(0);
+  L.cg = (int)coef.size();
+  auto refl = [](int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+  };
+  bool ok = true;
+  const int G = (L.w + 2 * SD_EDGE + 3) / 4;
+  for (int gi = 0; gi < G; gi++) {
+    int Xr[4], sx[4] = {0, 0, 0, 0};
+    uint32_t ab[4] = {0, 0, 0, 0}, selP[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; k++) Xr[k] = refl(4 * gi - SD_EDGE + k, L.w);
+    int base = 0;
+    if (xo) {
+      for (int k = 0; k < 4; k++) {
+        sx[k] = (*xo)[Xr[k]];
+        ab[k] = (uint32_t)(*xa)[Xr[k]];
+      }
+      base = std::min(std::min(sx[0], sx[1]), std::min(sx[2], sx[3]));
+      for (int k = 0; k < 4; k++) {
+        const int o = sx[k] - base, o1 = std::min(sx[k] + 1, src_w - 1) - base;
+        if (o < 0 || o > 7 || o1 < 0 || o1 > 7) ok = false;
+        selP[k] = (uint32_t)o | 0x0c00u | ((uint32_t)o1 << 16) | 0x0c000000u;
+      }
+    }
+    const int Xmin = std::min(std::min(Xr[0], Xr[1]), std::min(Xr[2], Xr[3]));
+    uint32_t sel0 = 0;
+    for (int k = 0; k < 4; k++) {
+      if (Xr[k] - Xmin > 3) ok = false;
+      sel0 |= (uint32_t)((Xr[k] - Xmin) & 3) << (8 * k);
+    }
+    const int32_t e[12] = {base, (int32_t)selP[0], (int32_t)selP[1], (int32_t)selP[2], (int32_t)selP[3], (int32_t)ab[0], (int32_t)ab[1],
+                           (int32_t)ab[2], (int32_t)ab[3], Xmin, (int32_t)sel0, 0};
+    coef.insert(coef.end(), e, e + 12);
+  }
+  return ok;
+}
+
 bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPlan& hp, const char** why) {
   (void)nfeatures;
   if (nlevels < 1 || nlevels > SD_MAX_LEVELS) { *why = "nlevels out of range"; return false; }
@@ -121,7 +165,7 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
     // resize tables (level l from level l-1)
     L.area2x2 = 0;
     L.fast_resize = 0;
-    L.cx = L.cy = 0;
+    L.cx = L.cy = L.cg = 0;
     L.scale_x = L.scale_y = 1.0;
     if (l > 0) {
       const LevelGeom& S = P.lv[l - 1];
@@ -144,14 +188,19 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
         hp.coef.insert(hp.coef.end(), yb.begin(), yb.end());
         // k_pyr_resize gathers the sources of 4 adjacent outputs out of 8 consecutive source bytes
         bool ok = L.w >= 8;
-        for (int x0 = 1; ok && x0 + 3 < L.w; x0 += 4)
+        // (every run of 4 consecutive outputs: the border groups of a padded row are such runs at reflected positions, in any order)
+        for (int x0 = 0; ok && x0 + 3 < L.w; x0++)
           if (std::min(xo[x0 + 3] + 1, S.w - 1) - xo[x0] > 7 || xo[x0 + 3] < xo[x0]) ok = false;
         for (int x = 0; ok && x < L.w; x++)
           if ((xa[x] & 0xffff) > 2048 || ((uint32_t)xa[x] >> 16) > 2048) ok = false;
         for (int y = 0; ok && y < L.h; y++)
           if (yo[y] < 0 || (yb[y] & 0xffff) > 2048 || ((uint32_t)yb[y] >> 16) > 2048) ok = false;
         L.fast_resize = ok ? 1 : 0;
+        if (ok) ok = group_table(L, S.w, &xo, &xa, hp.coef);
+        L.fast_resize = ok ? 1 : 0;
       }
+    } else {
+      L.fast_resize = group_table(L, 0, nullptr, nullptr, hp.coef) ? 1 : 0;   // level 0: the copy of the frame uses the column part only
     }
 
     // grid (src/ORBextractor.cc:472-488)
