@@ -342,8 +342,7 @@ __device__ __forceinline__ void pyr_resize_body(const LevelGeom& L, const LevelG
       packed[r] = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(q1, q[0], o & 3u), sel);
     }
   } else {
-    const int32_t* yo = coef + L.cy;
-    const int32_t* yb = yo + L.h;
+    const int4* rt = (const int4*)(coef + L.cr);   // per interior row: byte offsets of its two source rows, vertical coefficient pair
     const int4 t0 = gt[0], t1 = gt[1], t2 = gt[2];
     const int base = t0.x;
     // v_perm selector per output pixel: {left source byte, 0, right source byte, 0} of the row's 8-byte window = the two
@@ -356,13 +355,9 @@ __device__ __forceinline__ void pyr_resize_body(const LevelGeom& L, const LevelG
     unsigned shv[PYR_RPT];
 #pragma unroll
     for (int r = 0; r < PYR_RPT; r++) {   // all loads of both rows first
-      int sy0 = yo[(uint32_t)Yr[r]];
-      bbv[r] = (uint32_t)yb[(uint32_t)Yr[r]];
-      int sy1 = sy0 + 1;
-      sy0 = sy0 < S.h ? sy0 : S.h - 1;
-      sy1 = sy1 < S.h ? sy1 : S.h - 1;
-      const uint32_t a0 = (uint32_t)(__mul24(sy0 + SD_EDGE, S.pstride) + base + SD_EDGE);
-      const uint32_t a1 = (uint32_t)(__mul24(sy1 + SD_EDGE, S.pstride) + base + SD_EDGE);
+      const int4 tr = rt[Yr[r]];
+      bbv[r] = (uint32_t)tr.z;
+      const uint32_t a0 = (uint32_t)(tr.x + base), a1 = (uint32_t)(tr.y + base);
       shv[r] = a0 & 3u;   // same for both source rows: the row pitch is a multiple of 64
       const uint32_t* q0 = (const uint32_t*)(sb + (a0 & ~3u));
       const uint32_t* q1 = (const uint32_t*)(sb + (a1 & ~3u));

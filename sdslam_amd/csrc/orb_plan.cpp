@@ -165,7 +165,7 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
     // resize tables (level l from level l-1)
     L.area2x2 = 0;
     L.fast_resize = 0;
-    L.cx = L.cy = L.cg = 0;
+    L.cx = L.cy = L.cg = L.cr = 0;
     L.scale_x = L.scale_y = 1.0;
     if (l > 0) {
       const LevelGeom& S = P.lv[l - 1];
@@ -197,6 +197,17 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
           if (yo[y] < 0 || (yb[y] & 0xffff) > 2048 || ((uint32_t)yb[y] >> 16) > 2048) ok = false;
         L.fast_resize = ok ? 1 : 0;
         if (ok) ok = group_table(L, S.w, &xo, &xa, hp.coef);
+        if (ok) {   // per-row table: where the two source rows start inside the padded source level (column 0 of the interior)
+          while (hp.coef.size() % 4) hp.coef.push_back(0);
+          L.cr = (int)hp.coef.size();
+          for (int y = 0; y < L.h; y++) {
+            const int sy0 = std::min(yo[y], S.h - 1), sy1 = std::min(yo[y] + 1, S.h - 1);
+            hp.coef.push_back((sy0 + SD_EDGE) * S.pstride + SD_EDGE);
+            hp.coef.push_back((sy1 + SD_EDGE) * S.pstride + SD_EDGE);
+            hp.coef.push_back(yb[y]);
+            hp.coef.push_back(0);
+          }
+        }
         L.fast_resize = ok ? 1 : 0;
       }
     } else {

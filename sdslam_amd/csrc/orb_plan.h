@@ -27,6 +27,7 @@ struct LevelGeom {
   int sel_off;           // first slot of this level in the per-frame selected-key array
   int area2x2;           // resize takes the exact-2x INTER_AREA fast path
   int cx, cy;            // offsets of the x / y resize tables inside the coefficient array: {ofs[dn], a0|a1<<16 [dn]}
+  int cr;                // offset of the per-row table of k_pyr_split (4 dwords per interior row: byte offsets of the two source rows, b0|b1<<16, 0)
   int cg;                // offset of the per-group table of k_pyr_split (12 dwords per 4-pixel group of a padded row, 16-byte aligned)
   int fast_resize;       // level qualifies for k_pyr_resize (bilinear, 4 outputs read <= 8 source bytes)
   double scale_x, scale_y;   // cv::resize: 1. / ((double)dst / src) from level l-1 to l
