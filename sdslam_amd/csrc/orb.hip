@@ -270,10 +270,11 @@ __global__ __launch_bounds__(256) void k_pyr_level(const LevelGeom L, const Leve
 // per-byte path pyr_px4: a fifth of every launch's workgroups.)  Level 0 is the frame copied into the padded layout by the same kernel.
 // ------------------------------------------------------------------------------------------
 #ifndef PYR_RPT
-#define PYR_RPT 3
+#define PYR_RPT 4
 #endif
-// rows per thread: rows Y, Y + ceil(h / 3), Y + 2 ceil(h / 3) share the x coefficients and give three independent load chains
-// (A/B on one box, full step: 3 rows 130.8 k, 2 rows 130.4 k frames/s; 4 rows were no better than 2 in r01i)
+// rows per thread: rows Y, Y + ceil(h / 4), ... share the group's column data and give independent load chains (r1: 3 rows 130.8 k,
+// 2 rows 130.4 k frames/s, 4 rows no better than 2; r3, with the per-group / per-row tables as the fixed cost of a thread: 4 rows and
+// the descriptor patch on 8-byte loads 226.2 k vs 222.3 k with 3 rows, alternating runs)
 // **r2**: the rows are PADDED rows (0 .. h + 37): a top / bottom border row is the resize of its REFLECT_101 interior row, computed
 // here like any other row instead of being copied by a third kernel after the first two (k_pyr_rows, gone): ONE launch per level
 // (k_pyr_split), 8 pyramid launches per step instead of 24.  r3: where the level is tall enough for single reflections the border
@@ -1122,8 +1123,8 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 #ifndef DESC_KPW
 #define DESC_KPW 2   // keypoints per wave
 #endif
-#define DESC_PATCH_LD 6                       // dword loads per lane and keypoint: 6 x 64 >= 37 rows x 10 dwords
-#define DESC_PATCH_DW (DESC_PATCH_LD * 64)
+#define DESC_PATCH_LD 3                       // 8-byte loads per lane and keypoint: 3 x 64 >= 37 rows x 5 dword pairs
+#define DESC_PATCH_DW (2 * DESC_PATCH_LD * 64)
 __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__ P, const uint8_t* __restrict__ pyr,
                                                      const uint8_t* __restrict__ blur,
                                                      const uint32_t* __restrict__ sel,
@@ -1186,9 +1187,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
   // ---- the blurred 37 x 37 patch of each keypoint (the rotated test points reach +-18) goes to LDS as 37 rows of ten aligned
   // dwords, fetched NOW, beside the IC_Angle rows: the 512 sample reads of a keypoint were byte gathers over ~30 cache lines
   // per instruction that could only start once the angle was known
-  __shared__ uint32_t s_patch[4][DESC_KPW][DESC_PATCH_DW];
+  __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][DESC_KPW][DESC_PATCH_DW];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint32_t pdw[DESC_KPW][DESC_PATCH_LD];
+  uint2 pdw[DESC_KPW][DESC_PATCH_LD];
   int psh[DESC_KPW];
 #pragma unroll
   for (int q = 0; q < DESC_KPW; q++) {
@@ -1197,10 +1198,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
     const uint8_t* a4 = a - psh[q];
 #pragma unroll
     for (int k = 0; k < DESC_PATCH_LD; k++) {
-      const int e = min(k * 64 + lane, 37 * 10 - 1);
-      const int row = (int)(((unsigned)e * 6554u) >> 16);   // e / 10, e < 16384
-      const int d = e - row * 10;
-      pdw[q][k] = *(const uint32_t*)(a4 + (uint32_t)(__mul24(row, step[q]) + 4 * d));
+      const int e = min(k * 64 + lane, 37 * 5 - 1);
+      const int row = (int)(((unsigned)e * 13108u) >> 16);   // e / 5, e < 192
+      const int d = e - row * 5;
+      pdw[q][k] = *(const uint2*)(a4 + (uint32_t)(__mul24(row, step[q]) + 8 * d));   // 4-byte aligned: one global_load_dwordx2
     }
   }
 
@@ -1237,7 +1238,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbPlan* __restrict__
 #pragma unroll
     for (int q = 0; q < DESC_KPW; q++)
 #pragma unroll
-      for (int k = 0; k < DESC_PATCH_LD; k++) s_patch[wv][q][k * 64 + lane] = pdw[q][k];
+      for (int k = 0; k < DESC_PATCH_LD; k++) ((uint2*)s_patch[wv][q])[k * 64 + lane] = pdw[q][k];   // pair e = dwords 2 e, 2 e + 1 of the patch
     int vlim = -1;   // largest row index of this lane's column inside the disc (-1: lane outside)
 #pragma unroll
     for (int v = 0; v <= 15; v++) vlim += (act && au <= kUmax[v]) ? 1 : 0;

@@ -16,4 +16,4 @@ for v in ("full","base"):
     o=[json.load(open(f))["value"]/1e3 for f in sorted(glob.glob("gpurun_out/r3three_%s_orb[123].json"%v))]
     print(v, ["%.1f"%x for x in a], ["%.1f"%x for x in o])
 P
-unset SD_LIB; bash tools/trace_quick.sh full --orb-only | grep "k_pyr\|k_fast"
+unset SD_LIB; bash tools/trace_quick.sh full --orb-only | grep "k_pyr\|k_fast\|k_orient\|k_blur"
