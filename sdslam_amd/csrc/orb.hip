@@ -989,7 +989,7 @@ __global__ __launch_bounds__(64) void k_select_final(const OrbPlan* __restrict__
 #define BLUR_RB 32                  // output rows per wave
 #define SD_BLUR_SHIFT 1             // column offset of the blurred levels against the pyramid's layout (see k_blur)
 #ifndef BLUR_PF
-#define BLUR_PF 6                   // input rows in flight per thread
+#define BLUR_PF 8                   // input rows in flight per thread (r3, with the 16-lane groups: 8 rows ORB-only 287.8 k, 6 rows 284.4 k, 4 rows 281.1 k)
 #endif
 
 __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, const BlurTile* __restrict__ tiles,
