@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_pyr_level(const LevelGeom L, const Leve
 #endif
 // rows per thread: rows Y, Y + ceil(h / 4), ... share the group's column data and give independent load chains (r1: 3 rows 130.8 k,
 // 2 rows 130.4 k frames/s, 4 rows no better than 2; r3, with the per-group / per-row tables as the fixed cost of a thread: 4 rows and
-// the descriptor patch on 8-byte loads 226.2 k vs 222.3 k with 3 rows, alternating runs)
+// the descriptor patch on 8-byte loads 226.2 k vs 222.3 k with 3 rows; 4 / 5 / 6 rows 229.4 / 226.9 / 225.4 k, alternating runs)
 // **r2**: the rows are PADDED rows (0 .. h + 37): a top / bottom border row is the resize of its REFLECT_101 interior row, computed
 // here like any other row instead of being copied by a third kernel after the first two (k_pyr_rows, gone): ONE launch per level
 // (k_pyr_split), 8 pyramid launches per step instead of 24.  r3: where the level is tall enough for single reflections the border
