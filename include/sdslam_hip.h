@@ -68,6 +68,9 @@ typedef struct sd_keypoint {
  *   operator()      src/ORBextractor.h:45-46, src/ORBextractor.cc:620-678
  *   Get*()          src/ORBextractor.h:48-70
  * One handle serves frames up to max_w x max_h, at most max_batch frames per call.
+ * A geometry the kernels do not cover is refused with SD_ERR_INVALID_ARG and a message (sd_last_error, "unsupported geometry: ..."): image
+ * sides beyond 4095, a pyramid level that collapses to zero size, a grid cell whose FAST zone is one pixel wide (frames a few dozen
+ * pixels wide with hundreds of features per level).
  * ------------------------------------------------------------------------------------------ */
 typedef struct sd_orb sd_orb;
 

@@ -1005,7 +1005,8 @@ __global__ __launch_bounds__(256) void k_blur(const OrbPlan* __restrict__ P, con
   // fastest: the four groups of a wave read 256 contiguous columns wherever the level is that wide).  With a whole wave per 256
   // columns the levels' widths (640, 533, 444, 370, 309, 257, 214, 179) left a quarter of all lanes without a column.
   const int pr = T.p0 + wave * 4 + (lane >> 4);
-  const int band = (int)__umulhi((unsigned)pr, T.magic), strip = pr - band * T.nstrips;
+  // (a single strip has no 32-bit magic number: 2^32 / 1 does not fit)
+  const int band = T.nstrips == 1 ? pr : (int)__umulhi((unsigned)pr, T.magic), strip = pr - band * T.nstrips;
   const int x0 = strip * 64 + (lane & 15) * 4;
   const int y0 = band * BLUR_RB;
   if (x0 >= L.w || y0 >= L.h) return;

@@ -256,6 +256,9 @@ bool plan_geometry(int nfeatures, int nlevels, int thFAST, int w, int h, HostPla
           c.zy0 = iniY + 3;
           c.zw = ok ? hX - 6 : 0;
           c.zh = ok ? hY - 6 : 0;
+          // k_fast_cells walks a zone as one flat pixel range and recovers the row with a 32-bit multiply-high magic number, which
+          // does not exist for a divisor of 1 (frames a few dozen pixels wide with hundreds of features per level): refused, not guessed
+          if (c.zw == 1) { *why = "a grid cell's FAST zone is one pixel wide (frame too small for this many features per level)"; return false; }
           c.cap = ok ? (uint32_t)(((c.zw + 1) / 2) * ((c.zh + 1) / 2)) : 0;
           c.cand_off = cand;
           cand += c.cap;

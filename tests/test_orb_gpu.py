@@ -176,6 +176,27 @@ def test_more_geometries(sd, oracle, shape, cfg):
     ext.close()
 
 
+@pytest.mark.parametrize("shape", [(48, 64), (47, 67), (49, 65), (48, 200), (100, 63), (57, 77), (120, 66)])
+def test_pyramid_paths_at_their_size_thresholds(sd, oracle, shape):
+    """k_pyr_split switches paths by level size: border rows as second stores from 48 rows up (single reflections), branch-free
+    column reflection in the level-0 copy from 64 columns up, the per-group / per-row tables for every resized level.  Frames and
+    levels right at and around those limits (and widths with every residue of w + 38 mod 4): padded pyramid, keypoints and
+    descriptors equal the oracle's."""
+    H, W = shape
+    cfg = (150, 1.2, 3, 20)
+    frames = np.stack([np.ascontiguousarray(make_image(90 + i)[i * 7:i * 7 + H, i * 5:i * 5 + W]) for i in range(3)])
+    ext = sd.ORBextractor(*cfg, W, H, 3)
+    ora = oracle.OrbOracle(*cfg)
+    k, d, n = ext.extract_batch(frames)
+    for i in range(3):
+        ok, od = ora.extract(frames[i])
+        for l in range(cfg[2]):
+            assert np.array_equal(ext.level(l, i, padded=True), ora.level(l, padded=True)), f"pyramid level {l} of frame {i}"
+        assert n[i] == len(ok)
+        assert np.array_equal(k[i, :n[i]], ok) and np.array_equal(d[i, :n[i]], od)
+    ext.close()
+
+
 def test_errors_are_loud(sd):
     ext = sd.ORBextractor(1000, 1.2, 8, 20, 640, 480, 1)
     with pytest.raises(sd.SdError):
